@@ -1,0 +1,182 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own modules.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+
+What runs: ``clip.model.CLIP`` and ``trainers.mudpt.CustomCLIP`` imported unmodified from
+/root/reference; their parameters are overwritten with the seeded recipe of
+``oracle.mudpt_oracle.make_frozen_state`` / ``make_trainable_state`` so that tests can rebuild the
+same weights from (seed, rule) without storing them.  Four third-party packages the reference
+imports are absent from this image (yacs, dassl, ftfy, torchvision — SURVEY.md §8c); the
+generator puts inert placeholders for them on sys.path in a scratch directory: an attribute-dict
+``CfgNode``, a no-op trainer registry/base class, ``fix_text = identity`` and empty transform
+classes.  None of them touches arithmetic; every number in the fixtures comes out of the
+reference's code running on torch CPU fp32.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import mudpt_oracle as O  # noqa: E402
+
+REFERENCE = "/root/reference"
+CLASSNAMES = ["face", "leopard", "motorbike", "accordion", "airplane", "anchor", "ant", "barrel",
+              "bass", "beaver", "binocular"]  # first Caltech-101 names, SURVEY.md §8(d)
+
+PLACEHOLDERS = {
+    "yacs/__init__.py": "",
+    "yacs/config.py": """
+        class CfgNode(dict):
+            def __getattr__(self, k):
+                try:
+                    return self[k]
+                except KeyError:
+                    raise AttributeError(k)
+            def __setattr__(self, k, v):
+                self[k] = v
+        """,
+    "dassl/__init__.py": "",
+    "dassl/engine.py": """
+        class _Registry:
+            def register(self):
+                return lambda cls: cls
+        TRAINER_REGISTRY = _Registry()
+        class TrainerX:
+            pass
+        """,
+    "dassl/metrics.py": "def compute_accuracy(*a, **k):\n    raise NotImplementedError\n",
+    "dassl/utils.py": "def load_pretrained_weights(*a, **k):\n    raise NotImplementedError\n"
+                      "def load_checkpoint(*a, **k):\n    raise NotImplementedError\n",
+    "dassl/optim.py": "def build_optimizer(*a, **k):\n    raise NotImplementedError\n"
+                      "def build_lr_scheduler(*a, **k):\n    raise NotImplementedError\n",
+    "ftfy/__init__.py": "def fix_text(t):\n    return t\n",
+    "torchvision/__init__.py": "",
+    "torchvision/transforms.py": """
+        class _T:
+            def __init__(self, *a, **k):
+                pass
+        Compose = Resize = CenterCrop = ToTensor = Normalize = _T
+        class InterpolationMode:
+            BICUBIC = 3
+        """,
+}
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    d = tempfile.mkdtemp(prefix="mudpt_placeholders_")
+    for rel, src in PLACEHOLDERS.items():
+        p = os.path.join(d, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as f:
+            f.write(textwrap.dedent(src))
+    sys.path.insert(0, d)
+    sys.path.insert(0, REFERENCE)
+    import clip  # noqa: F401
+    from clip import model as clip_model
+    from trainers import mudpt
+    from yacs.config import CfgNode
+    return clip, clip_model, mudpt, CfgNode
+
+
+def seeded_images(cfg: O.Config, batch: int, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(batch, 3, cfg.image_size, cfg.image_size, generator=g)
+
+
+def run(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, train_seed: int,
+        image_seed: int, sample_big: bool):
+    clip, cm, mudpt, CN = import_reference()
+    ycfg = CN(TRAINER=CN(NAME="MuDPT", MUDPT=CN(N_CTX=cfg.n_ctx, CTX_INIT=ctx_init,
+                                                 DEEP_PROMPT_DEPTH=cfg.depth, PREC="fp32")),
+              INPUT=CN(SIZE=(cfg.image_size, cfg.image_size)))
+    ref_clip = cm.CLIP(cfg.embed_dim, cfg.image_size, cfg.v_layers, cfg.v_width, cfg.patch, cfg.ctx_len,
+                       cfg.vocab, cfg.t_width, cfg.t_heads, cfg.t_layers, ycfg).float()
+    frozen = O.make_frozen_state(cfg, frozen_seed)
+    missing, unexpected = ref_clip.load_state_dict(frozen, strict=False)
+    assert not unexpected, unexpected
+    assert all("visual_ctx" in k for k in missing), missing  # only the vision-side trainables
+    model = mudpt.CustomCLIP(ycfg, CLASSNAMES, ref_clip)
+
+    # ctx comes from the reference's own init (token embedding of ctx_init words, mudpt.py:57-64)
+    tok = model.tokenized_prompts
+    ctx_ids = [int(v) for v in clip.tokenize(ctx_init)[0, 1:1 + cfg.n_ctx]]
+    params = O.make_trainable_state(cfg, train_seed, frozen, ctx_ids)
+    ref_params = dict(model.named_parameters())
+    assert torch.equal(ref_params["mudpt_prompt_learner.ctx"].detach(), params["mudpt_prompt_learner.ctx"])
+    with torch.no_grad():
+        for k in O.TRAINABLE_ORDER:
+            ref_params[k].copy_(params[k])
+    # reference freeze rule, trainers/mudpt.py:205-212
+    for k, p in model.named_parameters():
+        p.requires_grad_("prompt_learner" in k or "visual_ctx" in k)
+    assert sorted(k for k, p in model.named_parameters() if p.requires_grad) == sorted(O.TRAINABLE_ORDER)
+
+    taps = {}
+
+    def hook(key):
+        def fn(_m, _i, out):
+            taps[key] = out[0].detach().permute(1, 0, 2).contiguous()  # LND -> NLD
+        return fn
+
+    for i, blk in enumerate(model.image_encoder.transformer.resblocks):
+        blk.register_forward_hook(hook(f"visual.transformer.resblocks.{i}.out"))
+    for i, blk in enumerate(model.text_encoder.transformer.resblocks):
+        blk.register_forward_hook(hook(f"transformer.resblocks.{i}.out"))
+
+    images = seeded_images(cfg, batch, image_seed)
+    labels = torch.arange(batch) * 3 % len(CLASSNAMES)
+    model.train()
+    logits = model(images)
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    grads = {k: ref_params[k].grad.detach().clone() for k in O.TRAINABLE_ORDER}
+
+    out = {
+        "config": np.array(repr(cfg.asdict())),
+        "classnames": np.array(CLASSNAMES),
+        "ctx_init": np.array(ctx_init),
+        "seeds": np.array([frozen_seed, train_seed, image_seed], dtype=np.int64),
+        "tokenized_prompts": tok.numpy().astype(np.int32),
+        "ctx_token_ids": np.array(ctx_ids, dtype=np.int32),
+        "labels": labels.numpy().astype(np.int64),
+        "images_checksum": np.array([images.double().sum().item(), images.double().abs().sum().item()]),
+        "frozen_checksum": np.array([frozen["visual.transformer.resblocks.0.attn.in_proj_weight"].double().sum().item(),
+                                     frozen["token_embedding.weight"].double().abs().sum().item()]),
+        "logits": logits.detach().numpy(),
+        "loss": np.array(loss.item(), dtype=np.float64),
+    }
+    for k in O.TRAINABLE_ORDER:
+        g = grads[k]
+        out["grad_sum." + k] = np.array([g.double().sum().item(), g.double().pow(2).sum().sqrt().item()])
+        if sample_big and g.dim() == 2 and g.numel() > 100000:
+            out["grad_sample." + k] = g[::8, ::8].numpy()  # strided sample of the big Linear weights
+        else:
+            out["grad." + k] = g.numpy()
+    keep = range(max(cfg.v_layers, cfg.t_layers)) if not sample_big else (0, 1, cfg.v_layers - 1)
+    for i in keep:
+        for pre in ("visual.transformer", "transformer"):
+            key = f"{pre}.resblocks.{i}.out"
+            if key in taps:
+                t = taps[key]
+                out["tap." + key] = (t[:, ::8, ::16] if sample_big else t).numpy()
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: loss {loss.item():.6f}, logits[0,:3] {logits[0, :3].tolist()}, "
+          f"{os.path.getsize(path) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    run(O.TINY, "mudpt_tiny", "a photo", batch=3, frozen_seed=11, train_seed=12, image_seed=13, sample_big=False)
+    run(O.VIT_B16, "mudpt_vitb16_b4", "a photo of a", batch=4, frozen_seed=0, train_seed=1, image_seed=1234,
+        sample_big=True)

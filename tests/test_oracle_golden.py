@@ -1,0 +1,69 @@
+"""Pin the CPU oracle to outputs of the reference's own modules (tests/golden/gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mudpt_oracle as O
+from tests.helpers import GoldenCase
+
+
+@pytest.fixture(scope="module", params=["mudpt_tiny", "mudpt_vitb16_b4"])
+def case(request):
+    c = GoldenCase(request.param)
+    c.check_recipe()
+    return c
+
+
+def test_forward_backward_matches_reference(case):
+    loss, logits, grads = O.forward_backward(case.cfg, case.frozen, case.params, case.class_embedding, case.eot,
+                                             case.images, case.labels)
+    # fp32 on both sides; only the summation order differs (batch-first vs LND, explicit softmax)
+    torch.testing.assert_close(logits, case.logits, atol=2e-5, rtol=1e-5)
+    assert abs(loss.item() - case.loss) < 1e-5
+    for k in O.TRAINABLE_ORDER:
+        g = grads[k]
+        s = case.z["grad_sum." + k]
+        assert abs(g.double().pow(2).sum().sqrt().item() - s[1]) <= 1e-4 * s[1] + 1e-9, k
+        full, sample = case.grad(k), case.grad_sample(k)
+        scale = float(s[1]) / max(g.numel() ** 0.5, 1.0)  # rms of the gradient tensor
+        if full is not None:
+            torch.testing.assert_close(g, full, atol=1e-3 * scale + 1e-9, rtol=1e-4)
+        else:
+            torch.testing.assert_close(g[::8, ::8], sample, atol=1e-3 * scale + 1e-9, rtol=1e-4)
+
+
+def test_block_outputs_match_reference(case):
+    taps = {}
+    with torch.no_grad():
+        O.forward(case.cfg, case.frozen, case.params, case.class_embedding, case.eot, case.images, taps)
+    n = 0
+    for k in case.z.files:
+        if not k.startswith("tap."):
+            continue
+        ref = torch.from_numpy(case.z[k])
+        got = taps[k[4:]]
+        if got.shape != ref.shape:
+            got = got[:, ::8, ::16]
+        torch.testing.assert_close(got, ref, atol=2e-4, rtol=1e-4)
+        n += 1
+    assert n >= 6
+
+
+def test_tokenizer_fixture_shape(case):
+    tok = case.tokens
+    assert tok.shape == (11, 77)
+    assert (tok[:, 0] == 49406).all() and (tok.max(dim=-1).values == 49407).all()
+    # "a photo of a <name>." -> EOT at 7 for one-token names, 8 for "binocular" (n_ctx 4)
+    if case.cfg.n_ctx == 4:
+        assert case.eot.tolist() == [7] * 10 + [8]
+
+
+def test_flat_bucket_roundtrip():
+    cfg = O.TINY
+    p = O.make_trainable_state(cfg, 3)
+    flat = O.flatten(p)
+    assert flat.numel() == sum(v.numel() for v in p.values())
+    q = O.unflatten(flat, cfg)
+    for k in O.TRAINABLE_ORDER:
+        assert torch.equal(p[k], q[k])
+    assert O.flatten(O.make_trainable_state(O.VIT_B16, 1)).numel() == 1243136
