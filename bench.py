@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MuDPT ViT-B/16 forward+backward(+SGD step) images/s, batch 256 per MI355X, bf16.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = BASELINE.json configs[1]: forward + cross-entropy + backward through both prompted CLIP towers
+for 256 synthetic 224x224 images and 11 class prompts (n_ctx 4, depth 12), the RCCL all-reduce of the 10
+trainable tensors when N > 1, and the SGD update.  Inputs, weights and parameters are resident in HBM before
+the timed region.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_TFLOPS = 2500.0  # gfx950 dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, spec)
+
+
+def flops_per_step(shape, B: int, C: int) -> float:
+    """Algorithmic FLOPs of one step: per token per block GEMM 24 d^2 and attention 4 L d forward;
+    backward = dX-only GEMMs (1x forward) + attention 2x forward; patch embed forward only; text tower once per step."""
+    def tower(d, L, layers):
+        return L * layers * (2 * 24 * d * d + 3 * 4 * L * d)
+    P = (shape.image_size // shape.patch) ** 2
+    Lv = 1 + P + shape.n_ctx
+    vis = tower(shape.v_width, Lv, shape.v_layers) + 2 * P * (3 * shape.patch ** 2) * shape.v_width
+    txt = tower(shape.t_width, shape.ctx_len, shape.t_layers)
+    return float(B) * vis + float(C) * txt
+
+
+def cpu_baseline(iters: int = 8):
+    """The CPU oracle (oracle/, a restatement of the reference's arithmetic pinned by tests/golden) timed on the host
+    cores at BASELINE config 1's shape: ViT-B/16, n_ctx 4, depth 12, batch 4, 11 classes, fp32."""
+    from oracle import mudpt_oracle as O
+    from mudpt_amd.synth import bench_tokenized_prompts, CTX_INIT_TOKENS
+    cfg = O.VIT_B16
+    frozen = O.make_frozen_state(cfg, 0)
+    tok = bench_tokenized_prompts().long()
+    emb, eot = frozen["token_embedding.weight"][tok], tok.argmax(-1)
+    params = O.make_trainable_state(cfg, 1, frozen, CTX_INIT_TOKENS)
+    g = torch.Generator().manual_seed(1234)
+    images, labels = torch.randn(4, 3, 224, 224, generator=g), torch.tensor([0, 3, 6, 9])
+    times = []
+    for i in range(2 + iters):
+        t0 = time.perf_counter()
+        O.forward_backward(cfg, frozen, params, emb, eot, images, labels)
+        if i >= 2:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(4 / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} fwd+bwd iterations of BASELINE config 1 (batch 4, 11 classes, fp32), median {med * 1e3:.0f} ms"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--classes", type=int, default=11)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the MuDPT path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")  # RCCL over xGMI
+
+    from mudpt_amd.model import CustomCLIP, ModelShape
+    from mudpt_amd import synth
+    shape = ModelShape()  # CLIP ViT-B/16, n_ctx 4, depth 12
+    B, C = args.batch, args.classes
+    tok = synth.bench_tokenized_prompts() if C == 11 else synth.synthetic_tokenized_prompts(C)
+    model = CustomCLIP(shape, synth.random_clip_state(shape, seed=0), tok, ctx_token_ids=synth.CTX_INIT_TOKENS,
+                       max_batch=B, dtype=args.dtype, device=f"cuda:{local}", seed=1)  # same seeds on every rank: replicas
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = torch.randn(B, 3, shape.image_size, shape.image_size, generator=g).cuda()
+    labels = torch.randint(0, C, (B,), generator=g).cuda()
+    lr = 0.0025  # configs/trainers/MuDPT/vit_b16_bz4_ep10_nctx4_depth9.yaml OPTIM.LR
+
+    def step():
+        loss = model.forward_backward(images, labels, grad_scale=1.0 / world)
+        if dist is not None:
+            dist.all_reduce(model.flat_grads)  # ONE collective per step: the 4.97 MB bucket of the 10 trainable tensors
+        model.sgd_step(lr, momentum=0.9, weight_decay=5e-4)
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        model.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    gemm_ms, gemm_flop, gemm_n = model.profile_read() if not args.no_profile else (0.0, 0.0, 0)
+    model.profile(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss_v = float(loss.item())
+    if not (loss_v == loss_v) or abs(loss_v) == float("inf"):
+        raise SystemExit(f"non-finite loss {loss_v}")
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        step_flop = flops_per_step(shape, B, C)
+        out = {
+            "metric": "images/sec fwd+bwd ViT-B/16 MuDPT", "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"MuDPT ViT-B/16 fwd+bwd+SGD, batch {B}/GPU, {C} class prompts, n_ctx 4, depth 12, "
+                                   f"synthetic 224x224 N(0,1) images, random-init frozen CLIP (BASELINE configs[1])",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss_v, 4),
+                       "step_tflop": round(step_flop / 1e12, 3)},
+        }
+        if gemm_n:
+            ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None, "kernel": "gemm_nt_kernel (all MFMA GEMM launches)",
+                               "launches_per_step": gemm_n // args.steps, "avg_launch_us": round(gemm_ms * 1e3 / gemm_n, 2),
+                               "gemm_share_of_step": round(gemm_ms / (elapsed * 1e3), 4),
+                               "step_achieved": round(step_flop / (ms * 1e-3) / 1e12, 1), "step_frac": round(step_flop / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    model.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+/*
+ * mudpt.h -- C ABI of libmudpt_hip.so, the MI355X (gfx950) implementation of the MuDPT prompt-tuning
+ * hot path.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo):
+ *   mudpt_create / mudpt_set_weight      clip/model.py:881-921 build_model + CLIP.__init__ :667-779
+ *                                        (frozen weights ingested under OpenAI CLIP state-dict keys)
+ *   mudpt_set_class_prompts              trainers/mudpt.py:83-95   token_prefix / token_suffix buffers,
+ *                                        tokenized_prompts.argmax (EOT position, :154)
+ *   mudpt_param_* / mudpt_bind_params    trainers/mudpt.py:205-218 the 10 trainable tensors (freeze rule)
+ *   mudpt_forward                        trainers/mudpt.py:170-184 CustomCLIP.forward == model_inference()
+ *   mudpt_forward_backward               trainers/mudpt.py:249-251 forward, F.cross_entropy, backward
+ *   mudpt_sgd_step                       trainers/mudpt.py:251     model_backward_and_update's optimizer step
+ *   mudpt_gemm / _layernorm_* / _attention_*   the ATen ops under clip/model.py:164-175,257-301 (unit parity)
+ *
+ * Conventions: every function returns 0 on success or a MUDPT_ERR_* code; mudpt_last_error() gives
+ * the message of the calling thread's last failure.  No exceptions cross the ABI.  A model handle is
+ * not re-entrant.  Device pointers are HIP device memory owned by the caller unless stated; `stream`
+ * is a hipStream_t passed as void* (NULL = default stream).  All launches are asynchronous.
+ */
+#ifndef MUDPT_H
+#define MUDPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUDPT_ABI_VERSION 1
+
+#define MUDPT_OK 0
+#define MUDPT_ERR_ARG 1   /* bad argument / shape (the reference raises AssertionError, mudpt.py:52,55,190) */
+#define MUDPT_ERR_HIP 2   /* a HIP runtime call failed */
+#define MUDPT_ERR_STATE 3 /* call order: weights / prompts / parameters not set yet */
+
+#define MUDPT_BF16 0
+#define MUDPT_F16 1
+
+/* Model shape.  ViT-B/16 MuDPT: {224,16,768,12,12, 512,12,8,77, 512, 4,12, n_cls, max_batch, dtype}. */
+typedef struct mudpt_config {
+    int32_t image_size, patch, v_width, v_layers, v_heads;
+    int32_t t_width, t_layers, t_heads, ctx_len;
+    int32_t embed_dim;
+    int32_t n_ctx, depth; /* TRAINER.MUDPT.N_CTX / DEEP_PROMPT_DEPTH (train.py:115-119) */
+    int32_t n_cls;        /* number of class prompts */
+    int32_t max_batch;    /* activations are sized for this many images */
+    int32_t dtype;        /* MUDPT_BF16 / MUDPT_F16: MFMA operand type (fp32 accumulate, fp32 residual stream) */
+} mudpt_config;
+
+typedef struct mudpt_model mudpt_model;
+
+int mudpt_abi_version(void);
+const char* mudpt_last_error(void);
+
+int mudpt_create(const mudpt_config* cfg, mudpt_model** out);
+int mudpt_destroy(mudpt_model* m);
+
+/* Frozen weight by OpenAI CLIP state-dict key ("visual.transformer.resblocks.0.attn.in_proj_weight", ...),
+ * fp32 HOST data in the checkpoint's own layout; the library converts / transposes to its device layout.
+ * Keys the path does not use ("token_embedding.weight", ...) are accepted and ignored. */
+int mudpt_set_weight(mudpt_model* m, const char* key, const float* host_data, size_t numel);
+
+/* token_embedding(tokenized "<ctx words> <classname>.") [n_cls, ctx_len, t_width] fp32 HOST and the EOT
+ * position of every class prompt; rows 1..n_ctx are replaced by the trainable ctx at run time. */
+int mudpt_set_class_prompts(mudpt_model* m, const float* embedding, const int32_t* eot_index);
+
+/* The 10 trainable tensors live in ONE flat fp32 bucket (= the data-parallel all-reduce payload). */
+int mudpt_param_count(const mudpt_model* m);   /* 10 */
+size_t mudpt_param_numel(const mudpt_model* m); /* elements of the flat bucket */
+/* name = the reference's CustomCLIP state-dict key; shape has ndim entries (ndim <= 3). */
+int mudpt_param_info(const mudpt_model* m, int index, const char** name, size_t* offset, size_t* numel,
+                     int32_t* ndim, int64_t shape[3]);
+/* Device pointers to the flat parameter bucket and the flat gradient bucket (caller-owned, fp32). */
+int mudpt_bind_params(mudpt_model* m, float* params_dev, float* grads_dev);
+
+/* logits[B, n_cls] fp32 for images[B,3,S,S] fp32 (CLIP-normalised pixels), both device memory. */
+int mudpt_forward(mudpt_model* m, const float* images_dev, int32_t batch, float* logits_dev, void* stream);
+
+/* One training step's forward + backward: loss_dev[0] = mean cross-entropy over the batch, gradients of
+ * (grad_scale * loss) written to the bound gradient bucket.  logits_dev may be NULL.  grad_scale = 1/world
+ * makes the sum over data-parallel ranks the gradient of the global-batch mean. */
+int mudpt_forward_backward(mudpt_model* m, const float* images_dev, const int64_t* labels_dev, int32_t batch,
+                           float grad_scale, float* loss_dev, float* logits_dev, void* stream);
+
+/* torch.optim.SGD update of the bound parameters from the bound gradients (momentum buffer library-owned). */
+int mudpt_sgd_step(mudpt_model* m, float lr, float momentum, float weight_decay, float dampening,
+                   int32_t nesterov, void* stream);
+int mudpt_sgd_reset(mudpt_model* m);
+
+/* Test hook: copy an internal fp32 activation of the last call to HOST memory (synchronises the device).
+ * name: "vis.x_in.<i>" / "txt.x_in.<i>" (input of block i, after the prompt splice), "vis.x_out" / "txt.x_out"
+ * (output of the last block), "image_features", "text_features".  host_out may be NULL to query *numel. */
+int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* host_out, size_t capacity, size_t* numel);
+
+/* Measurement hook (bench.py): bracket every MFMA GEMM launch of the path with HIP events on its launch stream.
+ * mudpt_profile_read synchronises and returns the summed duration, the summed algorithmic FLOPs (2 M N K) and
+ * the number of launches since the last enable / read. */
+int mudpt_profile_enable(mudpt_model* m, int32_t enable);
+int mudpt_profile_read(mudpt_model* m, double* gemm_ms, double* gemm_flop, int64_t* launches);
+
+/* ---- single kernels, exported for parity tests (all pointers device memory) ---------------------------- */
+/* epilogues: 0 store T | 1 bias+QuickGELU (out0 = u, out1 = gelu(u)) | 2 f32 out0 = aux + acc + bias |
+ *            3 out0 = acc * QuickGELU'(aux) | 4 patch-embed scatter + pos | 5 store f32 */
+int mudpt_gemm(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda,
+               const void* B, int32_t ldb, const float* bias, void* out0, int32_t ldo0, void* out1, int32_t ldo1,
+               const void* aux, int32_t ldaux, int32_t patches, int32_t seq_len, const float* pos, void* stream);
+int mudpt_layernorm_fwd(int32_t dtype, const float* x, int32_t ldx, const int32_t* row_index, const float* gamma,
+                        const float* beta, void* out, int32_t ldo, int32_t out_f32, float* mean, float* rstd,
+                        int32_t rows, int32_t d, void* stream);
+int mudpt_layernorm_bwd(int32_t dtype, const void* dy, int32_t lddy, int32_t dy_f32, const float* x, int32_t ldx,
+                        const int32_t* row_index, const float* mean, const float* rstd, const float* gamma,
+                        const float* dres, int32_t lddres, float* dx, int32_t lddx, void* dx_lp, int32_t lddx_lp,
+                        int32_t rows, int32_t d, void* stream);
+int mudpt_attention_padded_len(int32_t L);
+int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H,
+                        int32_t causal, void* stream);
+int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse,
+                        float* delta, void* dqkv, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUDPT_H */

@@ -1,0 +1,96 @@
+// Shared device/host definitions for the MuDPT gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mudpt {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// Operand dtype of the MFMA GEMMs / attention (fp32 accumulate, fp32 residual stream either way).
+enum DType : int { DT_BF16 = 0, DT_F16 = 1 };
+
+struct BF16 {
+    using elem = __bf16;
+    using vec8 = bf16x8;
+    using vec4 = bf16x4;
+    static constexpr int id = DT_BF16;
+    __device__ static inline f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+struct F16 {
+    using elem = _Float16;
+    using vec8 = f16x8;
+    using vec4 = f16x4;
+    static constexpr int id = DT_F16;
+    __device__ static inline f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ inline float quick_gelu(float u) {  // clip/model.py:173-175  x * sigmoid(1.702 x)
+    return u / (1.0f + __expf(-1.702f * u));
+}
+__device__ inline float quick_gelu_grad(float u) {
+    float s = 1.0f / (1.0f + __expf(-1.702f * u));
+    return s * (1.0f + 1.702f * u * (1.0f - s));
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Bijective XCD-aware remap of a 1-D grid: blocks that share an XCD (bid % 8) get one contiguous
+// chunk of work ids, so neighbouring tiles hit the same per-XCD L2 (speed only, never correctness).
+__device__ inline int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+}  // namespace mudpt
+
+// ---- host-side error plumbing (no exceptions cross the C ABI) -------------------------------
+#define MUDPT_OK 0
+#define MUDPT_ERR_ARG 1
+#define MUDPT_ERR_HIP 2
+#define MUDPT_ERR_STATE 3
+
+namespace mudpt {
+void set_error(const char* fmt, ...);
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            mudpt::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return MUDPT_ERR_HIP;                                                           \
+        }                                                                                   \
+    } while (0)
+
+#define ARG_CHECK(cond, ...)                                                                \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            mudpt::set_error(__VA_ARGS__);                                                  \
+            return MUDPT_ERR_ARG;                                                           \
+        }                                                                                   \
+    } while (0)

@@ -1,0 +1,278 @@
+// Small and HBM-bound kernels of the MuDPT path: patch im2col, prompt-row writes (the reference's
+// torch.cat splices, clip/model.py:288,296,530,536, become in-place row writes), the deterministic
+// batch reduction that is the splice's backward, the fp32 helpers for the prompt projections
+// (trainers/mudpt.py:127-128, clip/model.py:539), the cosine-logit / cross-entropy head
+// (trainers/mudpt.py:178-182,250) and the fused SGD update.
+#include "kernels.h"
+
+namespace mudpt {
+
+// ---- patchify: images fp32 [B,3,S,S] -> patches T [B*P, 3*p*p], inner order (c, py, px) = conv1.weight.reshape(out, -1)
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, typename T::elem* __restrict__ out, int B,
+                                                       int S, int p) {
+    using elem = typename T::elem;
+    const int x8n = S / 8;
+    const size_t total = (size_t)B * 3 * S * x8n;
+    const int g = S / p;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x8 = idx % x8n;
+        size_t t = idx / x8n;
+        const int y = t % S; t /= S;
+        const int c = t % 3;
+        const int b = t / 3;
+        const f32x4* src = (const f32x4*)(img + (((size_t)b * 3 + c) * S + y) * S + x8 * 8);
+        const f32x4 lo = src[0], hi = src[1];
+        const int gy = y / p, py = y % p, x = x8 * 8, gx = x / p, px = x % p;
+        typename T::vec8 v = {(elem)lo[0], (elem)lo[1], (elem)lo[2], (elem)lo[3], (elem)hi[0], (elem)hi[1], (elem)hi[2], (elem)hi[3]};
+        *(typename T::vec8*)(out + ((size_t)b * g * g + gy * g + gx) * (3 * p * p) + (c * p + py) * p + px) = v;
+    }
+}
+
+int launch_patchify(int dtype, const float* images, void* patches, int B, int S, int p, hipStream_t s) {
+    ARG_CHECK(images && patches && B > 0 && S > 0 && p > 0 && S % p == 0 && p % 8 == 0, "patchify: bad arguments S=%d p=%d", S, p);
+    const size_t total = (size_t)B * 3 * S * (S / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(patchify_kernel<BF16>, dim3(grid), dim3(256), 0, s, images, (__bf16*)patches, B, S, p);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(patchify_kernel<F16>, dim3(grid), dim3(256), 0, s, images, (_Float16*)patches, B, S, p);
+    else { set_error("patchify: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+// ---- set_rows: x[b, row0 + i, :] = rows[i, :] (+ add[i, :])
+__global__ __launch_bounds__(256) void set_rows_kernel(float* __restrict__ x, int L, int d, int row0, int n, const float* __restrict__ rows,
+                                                       const float* __restrict__ add) {
+    const int b = blockIdx.x / n, i = blockIdx.x % n;
+    f32x4* dst = (f32x4*)(x + ((size_t)b * L + row0 + i) * d);
+    const f32x4* r = (const f32x4*)(rows + (size_t)i * d);
+    const f32x4* a = add ? (const f32x4*)(add + (size_t)i * d) : nullptr;
+    for (int k = threadIdx.x; k < d / 4; k += blockDim.x) dst[k] = a ? r[k] + a[k] : r[k];
+}
+
+int launch_set_rows(float* x, int B, int L, int d, int row0, int n, const float* rows, const float* add, hipStream_t s) {
+    ARG_CHECK(x && rows && B > 0 && n > 0 && row0 >= 0 && row0 + n <= L && d % 4 == 0, "set_rows: bad arguments");
+    hipLaunchKernelGGL(set_rows_kernel, dim3(B * n), dim3(256), 0, s, x, L, d, row0, n, rows, add);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+// ---- reduce_rows: out[i, c] (+)= sum_b src[b, row0 + i, c] (b ascending: bitwise reproducible); optional zeroing
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(float* __restrict__ src, typename T::elem* __restrict__ src_lp, int B, int L, int d,
+                                                          int row0, int n, float* __restrict__ out, bool zero_src, bool accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    const int i = idx / d, c = idx % d;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const size_t o = ((size_t)b * L + row0 + i) * d + c;
+        acc += src[o];
+        if (zero_src) {
+            src[o] = 0.f;
+            if (src_lp) src_lp[o] = (typename T::elem)0.f;
+        }
+    }
+    out[idx] = accumulate ? out[idx] + acc : acc;
+}
+
+int launch_reduce_rows(int dtype, float* src, void* src_lp, int B, int L, int d, int row0, int n, float* out, bool zero_src,
+                       bool accumulate, hipStream_t s) {
+    ARG_CHECK(src && out && B > 0 && n > 0 && row0 >= 0 && row0 + n <= L, "reduce_rows: bad arguments");
+    const int grid = (n * d + 255) / 256;
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(reduce_rows_kernel<BF16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)src_lp, B, L, d, row0, n, out, zero_src, accumulate);
+    else if (dtype == DT_F16)
+        hipLaunchKernelGGL(reduce_rows_kernel<F16>, dim3(grid), dim3(256), 0, s, src, (_Float16*)src_lp, B, L, d, row0, n, out, zero_src, accumulate);
+    else { set_error("reduce_rows: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+// ---- small fp32 GEMM: C = alpha * op(A) op(B) + bias + beta * C, 16x16 tiles through LDS
+__global__ __launch_bounds__(256) void sgemm_kernel(bool tA, bool tB, int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
+                                                    const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
+                                                    const float* __restrict__ bias) {
+    __shared__ float As[16][17], Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        {   // As[ty][tx] = op(A)[m0 + ty][k0 + tx]
+            const int am = blockIdx.y * 16 + ty, ak = k0 + tx;
+            As[ty][tx] = (am < M && ak < K) ? (tA ? A[(size_t)ak * lda + am] : A[(size_t)am * lda + ak]) : 0.f;
+            // Bs[ty][tx] = op(B)[k0 + ty][n0 + tx]
+            const int bk = k0 + ty, bn = blockIdx.x * 16 + tx;
+            Bs[ty][tx] = (bk < K && bn < N) ? (tB ? B[(size_t)bn * ldb + bk] : B[(size_t)bk * ldb + bn]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += As[ty][k] * Bs[k][tx];
+        __syncthreads();
+    }
+    if (m < M && n < N) {
+        float v = alpha * acc;
+        if (bias) v += bias[n];
+        if (beta != 0.f) v += beta * C[(size_t)m * ldc + n];
+        C[(size_t)m * ldc + n] = v;
+    }
+}
+
+int launch_sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb, float beta,
+                 float* C, int ldc, const float* bias, hipStream_t s) {
+    ARG_CHECK(A && B && C && M > 0 && N > 0 && K > 0, "sgemm: bad arguments M=%d N=%d K=%d", M, N, K);
+    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, s, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int M, int N, int lda, float* __restrict__ out, bool accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc += A[(size_t)m * lda + n];
+    out[n] = accumulate ? out[n] + acc : acc;
+}
+
+int launch_colsum(const float* A, int M, int N, int lda, float* out, bool accumulate, hipStream_t s) {
+    ARG_CHECK(A && out && M > 0 && N > 0, "colsum: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, A, M, N, lda, out, accumulate);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a[i] + b[i];
+}
+
+int launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t s) {
+    ARG_CHECK(a && b && y && n > 0, "add: bad arguments");
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(add_kernel, dim3(grid), dim3(256), 0, s, a, b, y, n);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, typename T::elem* __restrict__ y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (typename T::elem)x[i];
+}
+
+int launch_cast(int dtype, const float* x, void* y, size_t n, hipStream_t s) {
+    ARG_CHECK(x && y && n > 0, "cast: bad arguments");
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(cast_kernel<BF16>, dim3(grid), dim3(256), 0, s, x, (__bf16*)y, n);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(cast_kernel<F16>, dim3(grid), dim3(256), 0, s, x, (_Float16*)y, n);
+    else { set_error("cast: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+// ---- head -------------------------------------------------------------------------------------------
+// y = x / ||x|| per row, inv = 1 / ||x||   (one wave per row)
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv, int rows, int e) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int i = lane; i < e; i += 64) { const float v = x[(size_t)r * e + i]; s += v * v; }
+    const float iv = 1.0f / sqrtf(wave_sum(s));
+    for (int i = lane; i < e; i += 64) y[(size_t)r * e + i] = x[(size_t)r * e + i] * iv;
+    if (lane == 0) inv[r] = iv;
+}
+// dx = inv * (dy - y * <dy, y>), in place on dy
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ inv, int rows, int e) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int i = lane; i < e; i += 64) s += dy[(size_t)r * e + i] * y[(size_t)r * e + i];
+    s = wave_sum(s);
+    const float iv = inv[r];
+    for (int i = lane; i < e; i += 64) dy[(size_t)r * e + i] = iv * (dy[(size_t)r * e + i] - y[(size_t)r * e + i] * s);
+}
+// per-row cross entropy: row_loss[b] = lse(logits[b]) - logits[b, label]; dlogits = (softmax - onehot) * gscale
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ row_loss,
+                                                      float* __restrict__ dlogits, int B, int C, float gscale) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B) return;
+    const float* z = logits + (size_t)r * C;
+    float m = -INFINITY;
+    for (int i = lane; i < C; i += 64) m = fmaxf(m, z[i]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < C; i += 64) s += __expf(z[i] - m);
+    s = wave_sum(s);
+    const int y = (int)labels[r];
+    if (lane == 0) row_loss[r] = (m + __logf(s)) - z[y];
+    if (dlogits) {
+        const float is = 1.f / s;
+        for (int i = lane; i < C; i += 64) dlogits[(size_t)r * C + i] = (__expf(z[i] - m) * is - (i == y ? 1.f : 0.f)) * gscale;
+    }
+}
+// loss = mean of row_loss in fixed order (one block, tree over a fixed partition: reproducible)
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float part[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0] / n;
+}
+
+static int check_head(const HeadArgs& a) {
+    ARG_CHECK(a.img && a.txt && a.logits && a.img_n && a.txt_n && a.img_inv && a.txt_inv, "head: null operand");
+    ARG_CHECK(a.B > 0 && a.C > 0 && a.e > 0, "head: bad shape B=%d C=%d e=%d", a.B, a.C, a.e);
+    return MUDPT_OK;
+}
+
+int launch_head_fwd(const HeadArgs& a, hipStream_t s) {
+    if (int e = check_head(a)) return e;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a.img, a.img_n, a.img_inv, a.B, a.e);
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((a.C + 3) / 4), dim3(256), 0, s, a.txt, a.txt_n, a.txt_inv, a.C, a.e);
+    HIP_TRY(hipGetLastError());
+    // logits = scale * img_n . txt_n^T
+    return launch_sgemm(false, true, a.B, a.C, a.e, a.scale, a.img_n, a.e, a.txt_n, a.e, 0.f, a.logits, a.C, nullptr, s);
+}
+
+int launch_head_bwd(const HeadArgs& a, hipStream_t s) {
+    if (int e = check_head(a)) return e;
+    ARG_CHECK(a.labels && a.loss && a.dlogits && a.row_loss && a.dimg && a.dtxt, "head bwd: null operand");
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a.logits, a.labels, a.row_loss, a.dlogits, a.B, a.C, a.grad_scale / a.B);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, a.row_loss, a.B, a.loss);
+    HIP_TRY(hipGetLastError());
+    // d img_n = scale * dlogits . txt_n ; d txt_n = scale * dlogits^T . img_n
+    if (int e = launch_sgemm(false, false, a.B, a.e, a.C, a.scale, a.dlogits, a.C, a.txt_n, a.e, 0.f, a.dimg, a.e, nullptr, s)) return e;
+    if (int e = launch_sgemm(true, false, a.C, a.e, a.B, a.scale, a.dlogits, a.C, a.img_n, a.e, 0.f, a.dtxt, a.e, nullptr, s)) return e;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a.dimg, a.img_n, a.img_inv, a.B, a.e);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((a.C + 3) / 4), dim3(256), 0, s, a.dtxt, a.txt_n, a.txt_inv, a.C, a.e);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+// ---- SGD (torch.optim.SGD update rule) ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n, float lr,
+                                                  float momentum, float wd, float dampening, bool nesterov, bool first) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float d = g[i] + wd * p[i];
+        if (momentum != 0.f) {
+            const float b = first ? d : momentum * buf[i] + (1.f - dampening) * d;
+            buf[i] = b;
+            d = nesterov ? d + momentum * b : b;
+        }
+        p[i] -= lr * d;
+    }
+}
+
+int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, float dampening, bool nesterov,
+               bool first, hipStream_t s) {
+    ARG_CHECK(p && g && n > 0 && (momentum == 0.f || buf), "sgd: bad arguments");
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, s, p, g, buf, n, lr, momentum, wd, dampening, nesterov, first);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+}  // namespace mudpt

@@ -1,0 +1,220 @@
+// MFMA GEMM for gfx950:  C[M,N] = A[M,K] . B[N,K]^T, bf16/fp16 operands, fp32 accumulate, fused epilogues.
+//
+// Replaces the reference's nn.Linear / conv-as-GEMM calls on the path (clip/model.py:257-263 in_proj,
+// out_proj, c_fc, c_proj; :527 conv1) and their autograd dX products.
+//
+// Structure (v1): BM x BN x 64 block tile, WM x WN waves, v_mfma_f32_16x16x32 tiles.  Both operand tiles
+// are staged global -> LDS with 16-byte global_load_lds (no VGPR round trip), double buffered.  The LDS
+// image of a tile is [rows][64] (128-byte rows); a wave instruction fills 8 rows.  global_load_lds writes
+// lane-linear, so the bank swizzle (16-byte chunk c of row r sits in slot c ^ (r & 7)) is applied on the
+// per-lane SOURCE address and again on the ds_read_b128 address; with it every 16-lane group of a
+// ds_read_b128 touches 16 distinct slots of the 256-byte bank row (conflict free).
+// The MFMA computes the transposed tile D[n][m] = B-frag x A-frag so that a lane owns 4 consecutive
+// output columns of one row: the epilogue stores 8 (T) or 16 (fp32) contiguous bytes per lane.
+#include "kernels.h"
+
+namespace mudpt {
+
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    constexpr int NW = WM * WN;
+    constexpr int BK = 64;
+    constexpr int TM = BM / WM / 16;  // 16-row sub-tiles per wave along M
+    constexpr int TN = BN / WN / 16;
+    constexpr int IA = BM / 8 / NW;   // global_load_lds instructions per wave for the A tile
+    constexpr int IB = BN / 8 / NW;
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over the waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int ntn = (p.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / ntn) * BM;
+    const int n0 = (wg % ntn) * BN;
+
+    const elem* __restrict__ A = (const elem*)p.A;
+    const elem* __restrict__ Bw = (const elem*)p.B;
+
+    // per-lane source pointers (k offset advances by BK per tile); rows clamped at the ragged edge
+    const int srow = lane >> 3;                       // row inside the 8-row group this lane fills
+    const int schunk = (lane & 7) ^ srow;             // swizzled source chunk for LDS slot (lane & 7)
+    const elem* asrc[IA];
+    const elem* bsrc[IB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        int r = m0 + (wave + NW * i) * 8 + srow;
+        r = r < p.M ? r : p.M - 1;
+        asrc[i] = A + (size_t)r * p.lda + schunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        int r = n0 + (wave + NW * i) * 8 + srow;
+        r = r < p.N ? r : p.N - 1;
+        bsrc[i] = Bw + (size_t)r * p.ldb + schunk * 8;
+    }
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < IA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(base + (wave + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < IB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + kt * BK), (lptr_t)(base + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row = sub-tile base + (lane & 15), chunk = 4 * kstep + (lane >> 4)
+    const int frow = lane & 15;
+    const int fq = lane >> 4;
+    int aoff[TM], boff[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) aoff[i] = (wm * (BM / WM) + i * 16 + frow) * 128;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) boff[j] = BM * 128 + (wn * (BN / WN) + j * 16 + frow) * 128;
+    const int sw = frow & 7;  // (row & 7): sub-tile bases are multiples of 16
+
+    const int nt = p.K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+        const char* base = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ((ks * 4 + fq) ^ sw) * 16;
+            vec8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const vec8*)(base + aoff[i] + c);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const vec8*)(base + boff[j] + c);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma16(bf[j], af[i], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds out[m][n .. n+3], m = sub-tile row (lane & 15), n = 4 * (lane >> 4) ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + frow;
+        if (m >= p.M) continue;
+        size_t orow = (size_t)m;
+        const float* posrow = nullptr;
+        if constexpr (EPI == EPI_PATCH) {
+            const int b = m / p.patches, pp = m - b * p.patches;
+            orow = (size_t)b * p.seq_len + 1 + pp;
+            posrow = p.pos + (size_t)(1 + pp) * p.N;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+            if (n >= p.N) continue;  // N % 16 == 0 is checked on the host: sub-tiles are all-in or all-out
+            f32x4 v = acc[i][j];
+            if (p.bias) {
+                const f32x4 b4 = *(const f32x4*)(p.bias + n);
+                v += b4;
+            }
+            if constexpr (EPI == EPI_STORE) {
+                typename T::vec4 o = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
+                *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = o;
+            } else if constexpr (EPI == EPI_GELU) {
+                typename T::vec4 u = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
+                typename T::vec4 g = {(elem)quick_gelu(v[0]), (elem)quick_gelu(v[1]), (elem)quick_gelu(v[2]),
+                                      (elem)quick_gelu(v[3])};
+                *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = u;
+                *(typename T::vec4*)((elem*)p.out1 + orow * p.ldo1 + n) = g;
+            } else if constexpr (EPI == EPI_RESIDUAL) {
+                const f32x4 r4 = *(const f32x4*)((const float*)p.aux + orow * p.ldaux + n);
+                *(f32x4*)((float*)p.out0 + orow * p.ldo0 + n) = v + r4;
+            } else if constexpr (EPI == EPI_GELU_BWD) {
+                const typename T::vec4 u = *(const typename T::vec4*)((const elem*)p.aux + orow * p.ldaux + n);
+                typename T::vec4 o = {(elem)(v[0] * quick_gelu_grad((float)u[0])), (elem)(v[1] * quick_gelu_grad((float)u[1])),
+                                      (elem)(v[2] * quick_gelu_grad((float)u[2])), (elem)(v[3] * quick_gelu_grad((float)u[3]))};
+                *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = o;
+            } else if constexpr (EPI == EPI_PATCH) {
+                const f32x4 q4 = *(const f32x4*)(posrow + n);
+                *(f32x4*)((float*)p.out0 + orow * p.ldo0 + n) = v + q4;
+            } else {  // EPI_STORE_F32
+                *(f32x4*)((float*)p.out0 + orow * p.ldo0 + n) = v;
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
+static int launch_cfg(const GemmArgs& a, hipStream_t s) {
+    constexpr int lds = 2 * (BM + BN) * 64 * 2;
+    auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+template <typename T, int EPI>
+static int launch_epi(const GemmArgs& a, hipStream_t s) {
+    // Large M: 256 x 128 tile on 8 waves (4 x 2, 64 x 64 per wave); small problems: 128 x 128 on 4 waves.
+    if ((size_t)a.M * a.N >= (size_t)256 * 128 * 512) return launch_cfg<T, 256, 128, 4, 2, EPI>(a, s);
+    return launch_cfg<T, 128, 128, 2, 2, EPI>(a, s);
+}
+
+template <typename T>
+static int launch_t(int epi, const GemmArgs& a, hipStream_t s) {
+    switch (epi) {
+        case EPI_STORE: return launch_epi<T, EPI_STORE>(a, s);
+        case EPI_GELU: return launch_epi<T, EPI_GELU>(a, s);
+        case EPI_RESIDUAL: return launch_epi<T, EPI_RESIDUAL>(a, s);
+        case EPI_GELU_BWD: return launch_epi<T, EPI_GELU_BWD>(a, s);
+        case EPI_PATCH: return launch_epi<T, EPI_PATCH>(a, s);
+        case EPI_STORE_F32: return launch_epi<T, EPI_STORE_F32>(a, s);
+    }
+    set_error("gemm: unknown epilogue %d", epi);
+    return MUDPT_ERR_ARG;
+}
+
+int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
+    ARG_CHECK(a.A && a.B && a.out0, "gemm: null operand");
+    ARG_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    ARG_CHECK(a.K % 64 == 0, "gemm: K=%d must be a multiple of 64", a.K);
+    ARG_CHECK(a.N % 16 == 0, "gemm: N=%d must be a multiple of 16", a.N);
+    ARG_CHECK(a.lda >= a.K && a.ldb >= a.K && a.lda % 8 == 0 && a.ldb % 8 == 0, "gemm: bad lda/ldb %d/%d", a.lda, a.ldb);
+    ARG_CHECK(a.ldo0 >= a.N && a.ldo0 % 4 == 0, "gemm: bad ldo0 %d", a.ldo0);
+    ARG_CHECK(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && ((uintptr_t)a.out0 % 16 == 0), "gemm: operands must be 16-byte aligned");
+    if (epi == EPI_GELU) ARG_CHECK(a.out1 && a.ldo1 >= a.N && a.ldo1 % 4 == 0, "gemm: gelu epilogue needs out1");
+    if (epi == EPI_RESIDUAL || epi == EPI_GELU_BWD) ARG_CHECK(a.aux && a.ldaux >= a.N && a.ldaux % 4 == 0, "gemm: epilogue needs aux");
+    if (epi == EPI_PATCH) ARG_CHECK(a.pos && a.patches > 0 && a.seq_len > a.patches && a.M % a.patches == 0, "gemm: bad patch epilogue args");
+    if (dtype == DT_BF16) return launch_t<BF16>(epi, a, s);
+    if (dtype == DT_F16) return launch_t<F16>(epi, a, s);
+    set_error("gemm: unknown dtype %d", dtype);
+    return MUDPT_ERR_ARG;
+}
+
+}  // namespace mudpt

@@ -1,0 +1,123 @@
+// Host-side launchers of the gfx950 kernels.  Every launcher validates operand shapes on the host
+// before the launch (a faulting kernel can reset the whole node) and returns MUDPT_OK / error code.
+#pragma once
+#include "common.h"
+
+namespace mudpt {
+
+// ------------------------------------------------------------------------------------------------
+// MFMA GEMM  C[M,N] = A[M,K] . B[N,K]^T  (both operands K-contiguous, dtype bf16 or fp16,
+// fp32 accumulate) with a fused epilogue.  nn.Linear stores weight [out,in] = B; the dX GEMMs of
+// the frozen layers use a pre-transposed copy of the weight, so one layout serves fwd and bwd.
+// ------------------------------------------------------------------------------------------------
+enum Epilogue : int {
+    EPI_STORE = 0,     // out0 (T)   = acc + bias
+    EPI_GELU = 1,      // out0 (T)   = u = acc + bias ; out1 (T) = QuickGELU(u)
+    EPI_RESIDUAL = 2,  // out0 (f32) = aux (f32) + acc + bias
+    EPI_GELU_BWD = 3,  // out0 (T)   = acc * QuickGELU'(aux (T))
+    EPI_PATCH = 4,     // out0 (f32) [(m / P) * L + 1 + m % P] = acc + pos[1 + m % P]   (patch embed)
+    EPI_STORE_F32 = 5  // out0 (f32) = acc + bias
+};
+
+struct GemmArgs {
+    const void* A = nullptr;  // [M, K], row stride lda (elements)
+    const void* B = nullptr;  // [N, K], row stride ldb
+    int M = 0, N = 0, K = 0, lda = 0, ldb = 0;
+    const float* bias = nullptr;  // [N] or null
+    void* out0 = nullptr; int ldo0 = 0;
+    void* out1 = nullptr; int ldo1 = 0;
+    const void* aux = nullptr; int ldaux = 0;
+    int patches = 0, seq_len = 0;  // EPI_PATCH: P, L
+    const float* pos = nullptr;    // EPI_PATCH: [1 + P, N]
+};
+int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (fp32 statistics, eps 1e-5; clip/model.py:164-170).
+// rows = number of normalised rows; row r reads x[row_index ? row_index[r] : r].
+// ------------------------------------------------------------------------------------------------
+struct LnFwdArgs {
+    const float* x = nullptr; int ldx = 0;     // fp32 input rows
+    const int* row_index = nullptr;            // optional gather of input rows
+    const float* gamma = nullptr; const float* beta = nullptr;
+    void* out = nullptr; int ldo = 0;          // T or fp32 (out_f32)
+    float* mean = nullptr; float* rstd = nullptr;  // [rows] saved statistics (may be null)
+    int rows = 0, d = 0; bool out_f32 = false;
+};
+int launch_ln_fwd(int dtype, const LnFwdArgs& a, hipStream_t s);
+
+struct LnBwdArgs {
+    const void* dy = nullptr; int lddy = 0; bool dy_f32 = false;  // grad of LN output (T or fp32), compact rows
+    const float* x = nullptr; int ldx = 0;    // LN input rows (gathered through row_index like fwd)
+    const int* row_index = nullptr;
+    const float* mean = nullptr; const float* rstd = nullptr; const float* gamma = nullptr;
+    const float* dres = nullptr; int lddres = 0;  // optional residual gradient added to the result (same row map as out)
+    float* dx = nullptr; int lddx = 0;        // fp32 result rows, written at row_index[r] (scatter) or r
+    void* dx_lp = nullptr; int lddx_lp = 0;   // optional T copy of the result
+    int rows = 0, d = 0;
+    bool by_token = false;  // dy / mean / rstd rows are indexed by the token row (row_index[r]) instead of r
+};
+int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Attention on packed qkv [B, L, 3*H*64] (q | k | v, heads contiguous inside each third), head dim 64.
+// ------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const void* qkv = nullptr;  // T [B, L, 3*H*64]
+    void* out = nullptr;        // fwd: T [B, L, H*64]
+    float* lse = nullptr;       // [B, H, Lp] natural-log-sum-exp of the scaled scores (Lp = padded L)
+    const void* dout = nullptr; // bwd: T [B, L, H*64]
+    void* dqkv = nullptr;       // bwd: T [B, L, 3*H*64]
+    float* delta = nullptr;     // bwd scratch [B, H, Lp]
+    int B = 0, L = 0, H = 0; bool causal = false;
+};
+int attn_padded_len(int L);
+int launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s);
+int launch_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Small / HBM-bound helpers
+// ------------------------------------------------------------------------------------------------
+// images fp32 [B,3,H,W] -> patches T [B*P, 3*p*p]  (im2col of the stride-p conv, clip/model.py:527-529)
+int launch_patchify(int dtype, const float* images, void* patches, int B, int image_size, int patch, hipStream_t s);
+// x[b, row0 + i, :] = rows[i, :] (+ add[i, :])  for i < n : CLS row, prompt rows, deep-prompt splice.
+int launch_set_rows(float* x, int B, int L, int d, int row0, int n, const float* rows, const float* add, hipStream_t s);
+// out[i, :] = sum_b src[b, row0 + i, :] in fixed order (deterministic); optionally zero the source rows
+// (fp32 and its T copy) afterwards: backward of the splice.  accumulate: out += instead of =.
+int launch_reduce_rows(int dtype, float* src, void* src_lp, int B, int L, int d, int row0, int n, float* out,
+                       bool zero_src, bool accumulate, hipStream_t s);
+// fp32 C[M,N] = alpha * op(A) . op(B) (+ bias[N]) (+ beta * C); small shapes only (prompt projections, head).
+int launch_sgemm(bool transA, bool transB, int M, int N, int K, float alpha, const float* A, int lda,
+                 const float* B, int ldb, float beta, float* C, int ldc, const float* bias, hipStream_t s);
+// out[n] (+)= sum_m A[m, n]
+int launch_colsum(const float* A, int M, int N, int lda, float* out, bool accumulate, hipStream_t s);
+// y = a + b (elementwise fp32)
+int launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t s);
+// cast fp32 -> T
+int launch_cast(int dtype, const float* x, void* y, size_t n, hipStream_t s);
+// Cosine-logit head + mean cross-entropy (trainers/mudpt.py:178-182,250), fwd and bwd in one launch each.
+struct HeadArgs {
+    const float* img = nullptr;   // [B, e] raw image features
+    const float* txt = nullptr;   // [C, e] raw text features
+    const int64_t* labels = nullptr;  // [B] (bwd / loss only)
+    float scale = 1.f;            // exp(logit_scale)
+    float* logits = nullptr;      // [B, C]
+    float* loss = nullptr;        // [1] mean CE over B (multiplied by loss_weight for the reported value? no: plain mean)
+    float* dlogits = nullptr;     // [B, C] scratch
+    float* row_loss = nullptr;    // [B] scratch
+    float* dimg = nullptr;        // [B, e] grad of raw image features
+    float* dtxt = nullptr;        // [C, e] grad of raw text features
+    float* img_n = nullptr;       // [B, e] scratch: normalised features
+    float* txt_n = nullptr;       // [C, e]
+    float* img_inv = nullptr;     // [B] 1/||img||
+    float* txt_inv = nullptr;     // [C]
+    float grad_scale = 1.f;       // multiplies dloss (1/world for data-parallel mean over the global batch)
+    int B = 0, C = 0, e = 0;
+};
+int launch_head_fwd(const HeadArgs& a, hipStream_t s);
+int launch_head_bwd(const HeadArgs& a, hipStream_t s);
+// Fused SGD (torch.optim.SGD semantics) over the flat bucket.
+int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
+               float dampening, bool nesterov, bool first_step, hipStream_t s);
+
+}  // namespace mudpt

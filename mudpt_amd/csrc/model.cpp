@@ -1,0 +1,723 @@
+// Host side of libmudpt_hip.so: owns the frozen weights and activations in HBM and sequences the
+// gfx950 kernels of one MuDPT forward / forward+backward on a HIP stream.
+//
+// Data layout in HBM (B images, C class prompts, ViT-B/16 numbers in brackets):
+//   tokens are batch-first [seq][L][d], never padded: vision L = 1 + P + n_ctx [201], text L = ctx_len [77];
+//   the residual stream and its gradient are fp32; GEMM / attention operands (LN output, qkv, attention
+//   output, MLP pre-activation, their gradients) are T = bf16 or fp16;
+//   frozen Linear weights are stored twice in T: [out,in] for the forward GEMM and [in,out] for the dX GEMM
+//   (weights are frozen, so the transposed copy is made once at load; no dW is ever computed);
+//   per block the backward needs x_in, x_mid (fp32), LN statistics, qkv, attention output + LSE and the
+//   MLP pre-activation: 0.95 GB per block at B = 256, 11.4 GB for the vision tower (288 GB HBM: no recompute).
+// Prompt rows are ordinary rows of the token buffer: the reference's torch.cat splices
+// (clip/model.py:281-297) are in-place row writes, their backward a fixed-order reduction over the batch.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/mudpt.h"
+#include "kernels.h"
+
+namespace mudpt {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// ---- host-side conversion to the operand dtype -----------------------------------------------------
+static inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline uint16_t f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct BlockW {
+    void *w_in = nullptr, *w_in_t = nullptr, *w_out = nullptr, *w_out_t = nullptr;
+    void *w_fc = nullptr, *w_fc_t = nullptr, *w_proj = nullptr, *w_proj_t = nullptr;
+    float *b_in = nullptr, *b_out = nullptr, *b_fc = nullptr, *b_proj = nullptr;
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+};
+
+struct BlockAct {
+    float *x_in = nullptr, *x_mid = nullptr;  // fp32 [M, d]
+    float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
+    void *qkv = nullptr, *attn = nullptr, *u = nullptr;  // T
+    float* lse = nullptr;
+};
+
+struct Tower {
+    int d = 0, layers = 0, heads = 0, L = 0, max_seq = 0, Lp = 0;
+    bool causal = false;
+    int prompt_row0 = 0;  // first prompt row inside a sequence (vision: L - n, text: 1)
+    std::vector<BlockW> w;
+    std::vector<BlockAct> a;  // layers entries; x_out of the last block lives in x_last
+    float* x_last = nullptr;
+    // scratch shared by all blocks
+    void *h = nullptr, *g = nullptr;                    // T [M,d], T [M,4d]
+    float* dx = nullptr; void* dx_lp = nullptr;         // gradient residual stream fp32 + T copy
+    void *dattn = nullptr, *dqkv = nullptr;             // T
+    float* delta = nullptr;
+};
+
+}  // namespace mudpt
+
+using namespace mudpt;
+
+struct mudpt_model {
+    mudpt_config cfg;
+    int dtype = 0;
+    std::vector<void*> allocs;
+    std::vector<std::string> missing;  // weight keys not yet set
+    bool prompts_set = false;
+
+    Tower vis, txt;
+    // vision stem / head
+    void* conv_w = nullptr;  // T [dv, 3 p p]
+    float *cls = nullptr, *vpos = nullptr, *ln_pre_g = nullptr, *ln_pre_b = nullptr, *ln_post_g = nullptr, *ln_post_b = nullptr;
+    float* vproj = nullptr;  // [dv, e]
+    void* patches = nullptr; // T [B P, 3 p p]
+    float *xpre = nullptr, *pre_mean = nullptr, *pre_rstd = nullptr;
+    float *f_ln = nullptr, *post_mean = nullptr, *post_rstd = nullptr, *df_ln = nullptr;
+    int *cls_rows = nullptr, *vprompt_rows = nullptr;
+    // text stem / head
+    float *tpos = nullptr, *ln_fin_g = nullptr, *ln_fin_b = nullptr, *tproj = nullptr;
+    float* emb_pos = nullptr;  // [C, Lt, dt] class token embeddings + positional embedding
+    int* eot_rows = nullptr;
+    float *t_ln = nullptr, *fin_mean = nullptr, *fin_rstd = nullptr, *dt_ln = nullptr;
+    float scale = 1.f;
+    // prompt learner intermediates (fp32)
+    float *shared = nullptr, *t2v = nullptr, *v2t = nullptr, *vis_deep = nullptr, *txt_deep = nullptr;
+    float *d_vis_deep = nullptr, *d_txt_deep = nullptr, *d_vprompt0 = nullptr;
+    // head
+    float *img_f = nullptr, *txt_f = nullptr, *img_n = nullptr, *txt_n = nullptr, *img_inv = nullptr, *txt_inv = nullptr;
+    float *logits = nullptr, *dlogits = nullptr, *row_loss = nullptr, *dimg = nullptr, *dtxt = nullptr, *loss = nullptr;
+    // parameters
+    float *params = nullptr, *grads = nullptr, *momentum = nullptr;
+    bool sgd_first = true;
+    size_t off[10];
+    size_t numel[10];
+    size_t total = 0;
+    // optional HIP-event timing of the MFMA GEMM launches (bench.py's roofline leg)
+    bool prof = false;
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t ev_used = 0;
+    std::vector<double> ev_flop;
+};
+
+// Every MFMA GEMM of the path goes through here; with profiling on, the launch is bracketed by HIP events on
+// the launch stream and its algorithmic FLOPs (2 M N K) are recorded.
+static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s) {
+    if (!m->prof) return launch_gemm(m->dtype, epi, a, s);
+    if (m->ev_used + 2 > m->ev.size()) {
+        for (int i = 0; i < 512; ++i) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            m->ev.push_back(e);
+        }
+    }
+    HIP_TRY(hipEventRecord(m->ev[m->ev_used], s));
+    const int rc = launch_gemm(m->dtype, epi, a, s);
+    HIP_TRY(hipEventRecord(m->ev[m->ev_used + 1], s));
+    m->ev_used += 2;
+    m->ev_flop.push_back(2.0 * a.M * a.N * a.K);
+    return rc;
+}
+
+static const char* kParamNames[10] = {
+    "mudpt_prompt_learner.ctx",
+    "mudpt_prompt_learner.deep_prompts",
+    "mudpt_prompt_learner.embed_projection.weight",
+    "mudpt_prompt_learner.embed_projection.bias",
+    "mudpt_prompt_learner.deep_projections.weight",
+    "mudpt_prompt_learner.deep_projections.bias",
+    "image_encoder.visual_ctx",
+    "image_encoder.visual_ctx_deep_prompts",
+    "image_encoder.visual_ctx_deep_projections.weight",
+    "image_encoder.visual_ctx_deep_projections.bias",
+};
+enum { P_CTX = 0, P_DEEP, P_EW, P_EB, P_DW, P_DB, P_VCTX, P_VDEEP, P_VW, P_VB };
+
+
+static int dev_alloc(mudpt_model* m, void** out, size_t bytes) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+    m->allocs.push_back(p);
+    *out = p;
+    return MUDPT_OK;
+}
+#define ALLOC(ptr, bytes)                                              \
+    do {                                                               \
+        if (int _e = dev_alloc(m, (void**)&(ptr), (size_t)(bytes))) return _e; \
+    } while (0)
+
+static int alloc_tower(mudpt_model* m, Tower& t, int d, int layers, int heads, int L, int max_seq, bool causal, int prompt_row0) {
+    t.d = d; t.layers = layers; t.heads = heads; t.L = L; t.max_seq = max_seq; t.causal = causal;
+    t.prompt_row0 = prompt_row0;
+    t.Lp = attn_padded_len(L);
+    const size_t M = (size_t)max_seq * L;
+    t.w.resize(layers);
+    t.a.resize(layers);
+    for (int i = 0; i < layers; ++i) {
+        BlockW& w = t.w[i];
+        ALLOC(w.w_in, (size_t)3 * d * d * 2); ALLOC(w.w_in_t, (size_t)3 * d * d * 2);
+        ALLOC(w.w_out, (size_t)d * d * 2); ALLOC(w.w_out_t, (size_t)d * d * 2);
+        ALLOC(w.w_fc, (size_t)4 * d * d * 2); ALLOC(w.w_fc_t, (size_t)4 * d * d * 2);
+        ALLOC(w.w_proj, (size_t)4 * d * d * 2); ALLOC(w.w_proj_t, (size_t)4 * d * d * 2);
+        ALLOC(w.b_in, 3 * d * 4); ALLOC(w.b_out, d * 4); ALLOC(w.b_fc, 4 * d * 4); ALLOC(w.b_proj, d * 4);
+        ALLOC(w.ln1_g, d * 4); ALLOC(w.ln1_b, d * 4); ALLOC(w.ln2_g, d * 4); ALLOC(w.ln2_b, d * 4);
+        BlockAct& a = t.a[i];
+        ALLOC(a.x_in, M * d * 4); ALLOC(a.x_mid, M * d * 4);
+        ALLOC(a.mean1, M * 4); ALLOC(a.rstd1, M * 4); ALLOC(a.mean2, M * 4); ALLOC(a.rstd2, M * 4);
+        ALLOC(a.qkv, M * 3 * d * 2); ALLOC(a.attn, M * d * 2); ALLOC(a.u, M * 4 * d * 2);
+        ALLOC(a.lse, (size_t)max_seq * heads * t.Lp * 4);
+    }
+    ALLOC(t.x_last, M * d * 4);
+    ALLOC(t.h, M * d * 2); ALLOC(t.g, M * 4 * d * 2);
+    ALLOC(t.dx, M * d * 4); ALLOC(t.dx_lp, M * d * 2);
+    ALLOC(t.dattn, M * d * 2); ALLOC(t.dqkv, M * 3 * d * 2);
+    ALLOC(t.delta, (size_t)max_seq * heads * t.Lp * 4);
+    return MUDPT_OK;
+}
+
+static void expect_block_keys(mudpt_model* m, const std::string& prefix, int layers) {
+    static const char* names[] = {"ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+                                  "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+                                  "mlp.c_proj.weight", "mlp.c_proj.bias"};
+    for (int i = 0; i < layers; ++i)
+        for (const char* n : names) m->missing.push_back(prefix + ".resblocks." + std::to_string(i) + "." + n);
+}
+
+extern "C" int mudpt_abi_version(void) { return MUDPT_ABI_VERSION; }
+extern "C" const char* mudpt_last_error(void) { return get_error(); }
+
+extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
+    ARG_CHECK(c && out, "create: null argument");
+    ARG_CHECK(c->dtype == MUDPT_BF16 || c->dtype == MUDPT_F16, "create: dtype must be MUDPT_BF16 or MUDPT_F16");
+    ARG_CHECK(c->depth > 0, "PROMPT_DEPTH should be > 0");  // trainers/mudpt.py:52
+    ARG_CHECK(c->n_ctx > 0 && c->n_cls > 0 && c->max_batch > 0, "create: n_ctx, n_cls, max_batch must be positive");
+    ARG_CHECK(c->image_size % c->patch == 0 && c->patch % 8 == 0, "create: image_size %d / patch %d unsupported", c->image_size, c->patch);
+    ARG_CHECK(c->v_width == c->v_heads * 64 && c->t_width == c->t_heads * 64, "create: head dim must be 64");
+    ARG_CHECK(c->v_width % 64 == 0 && c->t_width % 64 == 0 && c->v_width <= 1024 && c->t_width <= 1024, "create: widths must be multiples of 64, <= 1024");
+    ARG_CHECK(c->embed_dim == c->t_width, "create: embed_dim must equal t_width (visual_ctx_deep_projections output is added to text prompts)");
+    ARG_CHECK((3 * c->patch * c->patch) % 64 == 0, "create: 3*patch^2 must be a multiple of 64");
+    ARG_CHECK(1 + c->n_ctx < c->ctx_len, "create: n_ctx too large for ctx_len");
+    const int P = (c->image_size / c->patch) * (c->image_size / c->patch);
+    const int Lv = 1 + P + c->n_ctx;
+    ARG_CHECK(Lv <= 224 && c->ctx_len <= 224, "create: sequence length %d/%d exceeds the on-chip attention limit (224)", Lv, c->ctx_len);
+
+    mudpt_model* m = new mudpt_model();
+    m->cfg = *c;
+    m->dtype = c->dtype;
+    const int dv = c->v_width, dt = c->t_width, e = c->embed_dim, n = c->n_ctx, D1 = c->depth - 1, B = c->max_batch, C = c->n_cls;
+    auto fail = [&](int code) { mudpt_destroy(m); return code; };
+    if (int r = alloc_tower(m, m->vis, dv, c->v_layers, c->v_heads, Lv, B, false, Lv - n)) return fail(r);
+    if (int r = alloc_tower(m, m->txt, dt, c->t_layers, c->t_heads, c->ctx_len, C, true, 1)) return fail(r);
+    auto body = [&]() -> int {
+        const int K0 = 3 * c->patch * c->patch;
+        ALLOC(m->conv_w, (size_t)dv * K0 * 2);
+        ALLOC(m->cls, dv * 4); ALLOC(m->vpos, (size_t)(1 + P) * dv * 4);
+        ALLOC(m->ln_pre_g, dv * 4); ALLOC(m->ln_pre_b, dv * 4); ALLOC(m->ln_post_g, dv * 4); ALLOC(m->ln_post_b, dv * 4);
+        ALLOC(m->vproj, (size_t)dv * e * 4);
+        ALLOC(m->patches, (size_t)B * P * K0 * 2);
+        ALLOC(m->xpre, (size_t)B * Lv * dv * 4); ALLOC(m->pre_mean, (size_t)B * Lv * 4); ALLOC(m->pre_rstd, (size_t)B * Lv * 4);
+        ALLOC(m->f_ln, (size_t)B * dv * 4); ALLOC(m->post_mean, B * 4); ALLOC(m->post_rstd, B * 4); ALLOC(m->df_ln, (size_t)B * dv * 4);
+        ALLOC(m->cls_rows, B * 4); ALLOC(m->vprompt_rows, (size_t)B * n * 4);
+        ALLOC(m->tpos, (size_t)c->ctx_len * dt * 4); ALLOC(m->ln_fin_g, dt * 4); ALLOC(m->ln_fin_b, dt * 4);
+        ALLOC(m->tproj, (size_t)dt * e * 4);
+        ALLOC(m->emb_pos, (size_t)C * c->ctx_len * dt * 4); ALLOC(m->eot_rows, C * 4);
+        ALLOC(m->t_ln, (size_t)C * dt * 4); ALLOC(m->fin_mean, C * 4); ALLOC(m->fin_rstd, C * 4); ALLOC(m->dt_ln, (size_t)C * dt * 4);
+        const size_t dn = (size_t)(D1 > 0 ? D1 : 1) * n;
+        ALLOC(m->shared, (size_t)n * dv * 4); ALLOC(m->t2v, dn * dv * 4); ALLOC(m->v2t, dn * e * 4);
+        ALLOC(m->vis_deep, dn * dv * 4); ALLOC(m->txt_deep, dn * dt * 4);
+        ALLOC(m->d_vis_deep, dn * dv * 4); ALLOC(m->d_txt_deep, dn * dt * 4); ALLOC(m->d_vprompt0, (size_t)n * dv * 4);
+        ALLOC(m->img_f, (size_t)B * e * 4); ALLOC(m->txt_f, (size_t)C * e * 4); ALLOC(m->img_n, (size_t)B * e * 4); ALLOC(m->txt_n, (size_t)C * e * 4);
+        ALLOC(m->img_inv, B * 4); ALLOC(m->txt_inv, C * 4);
+        ALLOC(m->logits, (size_t)B * C * 4); ALLOC(m->dlogits, (size_t)B * C * 4); ALLOC(m->row_loss, B * 4);
+        ALLOC(m->dimg, (size_t)B * e * 4); ALLOC(m->dtxt, (size_t)C * e * 4); ALLOC(m->loss, 16);
+        // row index tables
+        std::vector<int> cr(B), pr((size_t)B * n);
+        for (int b = 0; b < B; ++b) {
+            cr[b] = b * Lv;
+            for (int i = 0; i < n; ++i) pr[(size_t)b * n + i] = b * Lv + (Lv - n) + i;
+        }
+        HIP_TRY(hipMemcpy(m->cls_rows, cr.data(), cr.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(m->vprompt_rows, pr.data(), pr.size() * 4, hipMemcpyHostToDevice));
+        return MUDPT_OK;
+    };
+    if (int r = body()) return fail(r);
+
+    // flat bucket layout, reference order/shapes: trainers/mudpt.py:71-81, clip/model.py:512-519
+    const size_t shapes[10] = {(size_t)n * dt, (size_t)D1 * n * dt, (size_t)dv * dt, (size_t)dv, (size_t)dv * dt, (size_t)dv,
+                               (size_t)n * dv, (size_t)D1 * n * dv, (size_t)e * dv, (size_t)e};
+    size_t o = 0;
+    for (int i = 0; i < 10; ++i) { m->off[i] = o; m->numel[i] = shapes[i]; o += shapes[i]; }
+    m->total = o;
+    if (int r = dev_alloc(m, (void**)&m->momentum, o * 4)) return fail(r);
+
+    // frozen weights the path needs before it may run
+    for (const char* k : {"visual.conv1.weight", "visual.class_embedding", "visual.positional_embedding", "visual.ln_pre.weight",
+                          "visual.ln_pre.bias", "visual.ln_post.weight", "visual.ln_post.bias", "visual.proj", "positional_embedding",
+                          "ln_final.weight", "ln_final.bias", "text_projection", "logit_scale"})
+        m->missing.push_back(k);
+    expect_block_keys(m, "visual.transformer", c->v_layers);
+    expect_block_keys(m, "transformer", c->t_layers);
+    *out = m;
+    return MUDPT_OK;
+}
+
+extern "C" int mudpt_destroy(mudpt_model* m) {
+    if (!m) return MUDPT_OK;
+    for (void* p : m->allocs) (void)hipFree(p);
+    for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+    delete m;
+    return MUDPT_OK;
+}
+
+// ---- weight ingestion -----------------------------------------------------------------------------------
+static int upload_f32(float* dst, const float* src, size_t n) {
+    HIP_TRY(hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice));
+    return MUDPT_OK;
+}
+// W [rows, cols] fp32 host -> T device, plain and (optionally) transposed copies
+static int upload_lp(int dtype, void* dst, void* dst_t, const float* src, size_t rows, size_t cols) {
+    std::vector<uint16_t> tmp(rows * cols);
+    auto cv = [&](float f) { return dtype == DT_BF16 ? f32_to_bf16(f) : f32_to_f16(f); };
+    for (size_t i = 0; i < rows * cols; ++i) tmp[i] = cv(src[i]);
+    HIP_TRY(hipMemcpy(dst, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    if (dst_t) {
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t c = 0; c < cols; ++c) tmp[c * rows + r] = cv(src[r * cols + c]);
+        HIP_TRY(hipMemcpy(dst_t, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    }
+    return MUDPT_OK;
+}
+
+static int set_block_weight(mudpt_model* m, Tower& t, int layer, const std::string& name, const float* data, size_t numel) {
+    ARG_CHECK(layer >= 0 && layer < t.layers, "set_weight: layer %d out of range", layer);
+    BlockW& w = t.w[layer];
+    const size_t d = t.d;
+    struct F32 { const char* n; float* p; size_t sz; };
+    const F32 f32s[] = {{"ln_1.weight", w.ln1_g, d}, {"ln_1.bias", w.ln1_b, d}, {"ln_2.weight", w.ln2_g, d}, {"ln_2.bias", w.ln2_b, d},
+                        {"attn.in_proj_bias", w.b_in, 3 * d}, {"attn.out_proj.bias", w.b_out, d}, {"mlp.c_fc.bias", w.b_fc, 4 * d},
+                        {"mlp.c_proj.bias", w.b_proj, d}};
+    for (const F32& f : f32s)
+        if (name == f.n) {
+            ARG_CHECK(numel == f.sz, "set_weight: %s expects %zu elements, got %zu", f.n, f.sz, numel);
+            return upload_f32(f.p, data, numel);
+        }
+    struct LP { const char* n; void* p; void* pt; size_t rows, cols; };
+    const LP lps[] = {{"attn.in_proj_weight", w.w_in, w.w_in_t, 3 * d, d}, {"attn.out_proj.weight", w.w_out, w.w_out_t, d, d},
+                      {"mlp.c_fc.weight", w.w_fc, w.w_fc_t, 4 * d, d}, {"mlp.c_proj.weight", w.w_proj, w.w_proj_t, d, 4 * d}};
+    for (const LP& l : lps)
+        if (name == l.n) {
+            ARG_CHECK(numel == l.rows * l.cols, "set_weight: %s expects %zu elements, got %zu", l.n, l.rows * l.cols, numel);
+            return upload_lp(m->dtype, l.p, l.pt, data, l.rows, l.cols);
+        }
+    set_error("set_weight: unknown block tensor '%s'", name.c_str());
+    return MUDPT_ERR_ARG;
+}
+
+extern "C" int mudpt_set_weight(mudpt_model* m, const char* key, const float* data, size_t numel) {
+    ARG_CHECK(m && key && data, "set_weight: null argument");
+    const mudpt_config& c = m->cfg;
+    const std::string k(key);
+    const size_t dv = c.v_width, dt = c.t_width, e = c.embed_dim;
+    const size_t P = (size_t)(c.image_size / c.patch) * (c.image_size / c.patch);
+    int rc = MUDPT_OK;
+    auto blk = [&](const char* prefix, Tower& t) -> int {
+        const std::string rest = k.substr(strlen(prefix));
+        const size_t dot = rest.find('.');
+        ARG_CHECK(dot != std::string::npos, "set_weight: malformed key %s", key);
+        return set_block_weight(m, t, atoi(rest.substr(0, dot).c_str()), rest.substr(dot + 1), data, numel);
+    };
+#define EXPECT(n) ARG_CHECK(numel == (size_t)(n), "set_weight: %s expects %zu elements, got %zu", key, (size_t)(n), numel)
+    if (k.rfind("visual.transformer.resblocks.", 0) == 0) rc = blk("visual.transformer.resblocks.", m->vis);
+    else if (k.rfind("transformer.resblocks.", 0) == 0) rc = blk("transformer.resblocks.", m->txt);
+    else if (k == "visual.conv1.weight") { EXPECT(dv * 3 * c.patch * c.patch); rc = upload_lp(m->dtype, m->conv_w, nullptr, data, dv, 3 * c.patch * c.patch); }
+    else if (k == "visual.class_embedding") { EXPECT(dv); rc = upload_f32(m->cls, data, numel); }
+    else if (k == "visual.positional_embedding") { EXPECT((1 + P) * dv); rc = upload_f32(m->vpos, data, numel); }
+    else if (k == "visual.ln_pre.weight") { EXPECT(dv); rc = upload_f32(m->ln_pre_g, data, numel); }
+    else if (k == "visual.ln_pre.bias") { EXPECT(dv); rc = upload_f32(m->ln_pre_b, data, numel); }
+    else if (k == "visual.ln_post.weight") { EXPECT(dv); rc = upload_f32(m->ln_post_g, data, numel); }
+    else if (k == "visual.ln_post.bias") { EXPECT(dv); rc = upload_f32(m->ln_post_b, data, numel); }
+    else if (k == "visual.proj") { EXPECT(dv * e); rc = upload_f32(m->vproj, data, numel); }
+    else if (k == "positional_embedding") { EXPECT((size_t)c.ctx_len * dt); rc = upload_f32(m->tpos, data, numel); m->prompts_set = false; }
+    else if (k == "ln_final.weight") { EXPECT(dt); rc = upload_f32(m->ln_fin_g, data, numel); }
+    else if (k == "ln_final.bias") { EXPECT(dt); rc = upload_f32(m->ln_fin_b, data, numel); }
+    else if (k == "text_projection") { EXPECT(dt * e); rc = upload_f32(m->tproj, data, numel); }
+    else if (k == "logit_scale") { EXPECT(1); m->scale = std::exp(data[0]); }  // trainers/mudpt.py:181
+    else if (k == "token_embedding.weight" || k == "input_resolution" || k == "context_length" || k == "vocab_size") return MUDPT_OK;
+    else { set_error("set_weight: unknown key '%s'", key); return MUDPT_ERR_ARG; }
+#undef EXPECT
+    if (rc) return rc;
+    for (size_t i = 0; i < m->missing.size(); ++i)
+        if (m->missing[i] == k) { m->missing.erase(m->missing.begin() + i); break; }
+    return MUDPT_OK;
+}
+
+extern "C" int mudpt_set_class_prompts(mudpt_model* m, const float* emb, const int32_t* eot) {
+    ARG_CHECK(m && emb && eot, "set_class_prompts: null argument");
+    for (const std::string& k : m->missing)
+        if (k == "positional_embedding") { set_error("set_class_prompts: set 'positional_embedding' first"); return MUDPT_ERR_STATE; }
+    const mudpt_config& c = m->cfg;
+    const size_t C = c.n_cls, L = c.ctx_len, d = c.t_width;
+    std::vector<float> pos(L * d), ep(C * L * d);
+    HIP_TRY(hipMemcpy(pos.data(), m->tpos, pos.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int> rows(C);
+    for (size_t cc = 0; cc < C; ++cc) {
+        ARG_CHECK(eot[cc] >= 0 && eot[cc] < (int)L, "set_class_prompts: eot index %d out of range", eot[cc]);
+        rows[cc] = (int)(cc * L) + eot[cc];
+        for (size_t i = 0; i < L * d; ++i) ep[cc * L * d + i] = emb[cc * L * d + i] + pos[i];  // trainers/mudpt.py:143
+    }
+    HIP_TRY(hipMemcpy(m->emb_pos, ep.data(), ep.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->eot_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+    m->prompts_set = true;
+    return MUDPT_OK;
+}
+
+extern "C" int mudpt_param_count(const mudpt_model*) { return 10; }
+extern "C" size_t mudpt_param_numel(const mudpt_model* m) { return m ? m->total : 0; }
+extern "C" int mudpt_param_info(const mudpt_model* m, int i, const char** name, size_t* offset, size_t* numel, int32_t* ndim, int64_t shape[3]) {
+    ARG_CHECK(m && i >= 0 && i < 10, "param_info: bad index %d", i);
+    const mudpt_config& c = m->cfg;
+    const int64_t n = c.n_ctx, D1 = c.depth - 1, dt = c.t_width, dv = c.v_width, e = c.embed_dim;
+    const int64_t shp[10][3] = {{n, dt, 0}, {D1, n, dt}, {dv, dt, 0}, {dv, 0, 0}, {dv, dt, 0}, {dv, 0, 0}, {n, dv, 0}, {D1, n, dv}, {e, dv, 0}, {e, 0, 0}};
+    const int nd[10] = {2, 3, 2, 1, 2, 1, 2, 3, 2, 1};
+    if (name) *name = kParamNames[i];
+    if (offset) *offset = m->off[i];
+    if (numel) *numel = m->numel[i];
+    if (ndim) *ndim = nd[i];
+    if (shape) for (int k = 0; k < 3; ++k) shape[k] = shp[i][k];
+    return MUDPT_OK;
+}
+extern "C" int mudpt_bind_params(mudpt_model* m, float* p, float* g) {
+    ARG_CHECK(m && p, "bind_params: null argument");
+    ARG_CHECK((uintptr_t)p % 16 == 0 && (uintptr_t)g % 16 == 0, "bind_params: buckets must be 16-byte aligned");
+    m->params = p;
+    m->grads = g;
+    return MUDPT_OK;
+}
+
+// ---- the path ---------------------------------------------------------------------------------------------
+#define TRY(expr)                      \
+    do {                               \
+        if (int _e = (expr)) return _e; \
+    } while (0)
+
+static int ready(mudpt_model* m, int B, bool need_grads) {
+    ARG_CHECK(m, "null model");
+    if (!m->missing.empty()) {
+        set_error("model not ready: %zu frozen weights unset (first: %s)", m->missing.size(), m->missing[0].c_str());
+        return MUDPT_ERR_STATE;
+    }
+    if (!m->prompts_set) { set_error("model not ready: call mudpt_set_class_prompts"); return MUDPT_ERR_STATE; }
+    if (!m->params) { set_error("model not ready: call mudpt_bind_params"); return MUDPT_ERR_STATE; }
+    if (need_grads && !m->grads) { set_error("model not ready: no gradient bucket bound"); return MUDPT_ERR_STATE; }
+    ARG_CHECK(B > 0 && B <= m->cfg.max_batch, "batch %d outside 1..max_batch=%d", B, m->cfg.max_batch);
+    return MUDPT_OK;
+}
+
+static float* out_of(Tower& t, int layer) { return layer + 1 < t.layers ? t.a[layer + 1].x_in : t.x_last; }
+
+static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
+    const int M = nseq * t.L, d = t.d, dt = m->dtype;
+    BlockW& w = t.w[i];
+    BlockAct& a = t.a[i];
+    LnFwdArgs l1; l1.x = a.x_in; l1.ldx = d; l1.gamma = w.ln1_g; l1.beta = w.ln1_b; l1.out = t.h; l1.ldo = d; l1.mean = a.mean1; l1.rstd = a.rstd1; l1.rows = M; l1.d = d;
+    TRY(launch_ln_fwd(dt, l1, s));
+    GemmArgs q; q.A = t.h; q.lda = d; q.B = w.w_in; q.ldb = d; q.M = M; q.N = 3 * d; q.K = d; q.bias = w.b_in; q.out0 = a.qkv; q.ldo0 = 3 * d;
+    TRY(gemm_call(m, EPI_STORE, q, s));
+    AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
+    TRY(launch_attn_fwd(dt, at, s));
+    GemmArgs o; o.A = a.attn; o.lda = d; o.B = w.w_out; o.ldb = d; o.M = M; o.N = d; o.K = d; o.bias = w.b_out; o.out0 = a.x_mid; o.ldo0 = d; o.aux = a.x_in; o.ldaux = d;
+    TRY(gemm_call(m, EPI_RESIDUAL, o, s));
+    LnFwdArgs l2; l2.x = a.x_mid; l2.ldx = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = d; l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = M; l2.d = d;
+    TRY(launch_ln_fwd(dt, l2, s));
+    GemmArgs f; f.A = t.h; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = M; f.N = 4 * d; f.K = d; f.bias = w.b_fc; f.out0 = a.u; f.ldo0 = 4 * d; f.out1 = t.g; f.ldo1 = 4 * d;
+    TRY(gemm_call(m, EPI_GELU, f, s));
+    GemmArgs p; p.A = t.g; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = M; p.N = d; p.K = 4 * d; p.bias = w.b_proj; p.out0 = out_of(t, i); p.ldo0 = d; p.aux = a.x_mid; p.ldaux = d;
+    TRY(gemm_call(m, EPI_RESIDUAL, p, s));
+    return MUDPT_OK;
+}
+
+// in: t.dx / t.dx_lp = gradient w.r.t. the block output; out: the same buffers = gradient w.r.t. x_in
+static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
+    const int M = nseq * t.L, d = t.d, dt = m->dtype;
+    BlockW& w = t.w[i];
+    BlockAct& a = t.a[i];
+    GemmArgs g1; g1.A = t.dx_lp; g1.lda = d; g1.B = w.w_proj_t; g1.ldb = d; g1.M = M; g1.N = 4 * d; g1.K = d; g1.out0 = t.g; g1.ldo0 = 4 * d; g1.aux = a.u; g1.ldaux = 4 * d;
+    TRY(gemm_call(m, EPI_GELU_BWD, g1, s));
+    GemmArgs g2; g2.A = t.g; g2.lda = 4 * d; g2.B = w.w_fc_t; g2.ldb = 4 * d; g2.M = M; g2.N = d; g2.K = 4 * d; g2.out0 = t.h; g2.ldo0 = d;
+    TRY(gemm_call(m, EPI_STORE, g2, s));
+    LnBwdArgs b2; b2.dy = t.h; b2.lddy = d; b2.x = a.x_mid; b2.ldx = d; b2.mean = a.mean2; b2.rstd = a.rstd2; b2.gamma = w.ln2_g; b2.dres = t.dx; b2.lddres = d;
+    b2.dx = t.dx; b2.lddx = d; b2.dx_lp = t.dx_lp; b2.lddx_lp = d; b2.rows = M; b2.d = d;
+    TRY(launch_ln_bwd(dt, b2, s));
+    GemmArgs g3; g3.A = t.dx_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = M; g3.N = d; g3.K = d; g3.out0 = t.dattn; g3.ldo0 = d;
+    TRY(gemm_call(m, EPI_STORE, g3, s));
+    AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.dout = t.dattn; at.dqkv = t.dqkv; at.delta = t.delta; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
+    TRY(launch_attn_bwd(dt, at, s));
+    GemmArgs g4; g4.A = t.dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 3 * d; g4.out0 = t.h; g4.ldo0 = d;
+    TRY(gemm_call(m, EPI_STORE, g4, s));
+    LnBwdArgs b1; b1.dy = t.h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.dres = t.dx; b1.lddres = d;
+    b1.dx = t.dx; b1.lddx = d; b1.dx_lp = t.dx_lp; b1.lddx_lp = d; b1.rows = M; b1.d = d;
+    TRY(launch_ln_bwd(dt, b1, s));
+    return MUDPT_OK;
+}
+
+static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t s) {
+    const mudpt_config& c = m->cfg;
+    const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, C = c.n_cls;
+    const int P = (c.image_size / c.patch) * (c.image_size / c.patch), Lv = m->vis.L, Lt = m->txt.L, K0 = 3 * c.patch * c.patch;
+    float* Pm = m->params;
+    // -- prompt learner, trainers/mudpt.py:117-130 + clip/model.py:534-539
+    TRY(launch_sgemm(false, true, n, dv, dt, 1.f, Pm + m->off[P_CTX], dt, Pm + m->off[P_EW], dt, 0.f, m->shared, dv, Pm + m->off[P_EB], s));
+    if (D1 > 0) {
+        TRY(launch_sgemm(false, true, D1 * n, dv, dt, 1.f, Pm + m->off[P_DEEP], dt, Pm + m->off[P_DW], dt, 0.f, m->t2v, dv, Pm + m->off[P_DB], s));
+        TRY(launch_sgemm(false, true, D1 * n, e, dv, 1.f, Pm + m->off[P_VDEEP], dv, Pm + m->off[P_VW], dv, 0.f, m->v2t, e, Pm + m->off[P_VB], s));
+        TRY(launch_add(m->t2v, Pm + m->off[P_VDEEP], m->vis_deep, (size_t)D1 * n * dv, s));
+        TRY(launch_add(m->v2t, Pm + m->off[P_DEEP], m->txt_deep, (size_t)D1 * n * dt, s));
+    }
+    // -- vision tower, clip/model.py:526-553
+    TRY(launch_patchify(m->dtype, images, m->patches, B, c.image_size, c.patch, s));
+    GemmArgs pe; pe.A = m->patches; pe.lda = K0; pe.B = m->conv_w; pe.ldb = K0; pe.M = B * P; pe.N = dv; pe.K = K0; pe.out0 = m->xpre; pe.ldo0 = dv;
+    pe.patches = P; pe.seq_len = Lv; pe.pos = m->vpos;
+    TRY(gemm_call(m, EPI_PATCH, pe, s));
+    TRY(launch_set_rows(m->xpre, B, Lv, dv, 0, 1, m->cls, m->vpos, s));
+    TRY(launch_set_rows(m->xpre, B, Lv, dv, Lv - n, n, Pm + m->off[P_VCTX], m->shared, s));
+    LnFwdArgs lp; lp.x = m->xpre; lp.ldx = dv; lp.gamma = m->ln_pre_g; lp.beta = m->ln_pre_b; lp.out = m->vis.a[0].x_in; lp.ldo = dv; lp.out_f32 = true;
+    lp.mean = m->pre_mean; lp.rstd = m->pre_rstd; lp.rows = B * Lv; lp.d = dv;
+    TRY(launch_ln_fwd(m->dtype, lp, s));
+    for (int i = 0; i < m->vis.layers; ++i) {
+        if (i >= 1 && i - 1 < D1) TRY(launch_set_rows(m->vis.a[i].x_in, B, Lv, dv, Lv - n, n, m->vis_deep + (size_t)(i - 1) * n * dv, nullptr, s));
+        TRY(block_fwd(m, m->vis, i, B, s));
+    }
+    LnFwdArgs lq; lq.x = m->vis.x_last; lq.ldx = dv; lq.row_index = m->cls_rows; lq.gamma = m->ln_post_g; lq.beta = m->ln_post_b; lq.out = m->f_ln; lq.ldo = dv;
+    lq.out_f32 = true; lq.mean = m->post_mean; lq.rstd = m->post_rstd; lq.rows = B; lq.d = dv;
+    TRY(launch_ln_fwd(m->dtype, lq, s));
+    TRY(launch_sgemm(false, false, B, e, dv, 1.f, m->f_ln, dv, m->vproj, e, 0.f, m->img_f, e, nullptr, s));
+    // -- text tower, trainers/mudpt.py:142-156
+    HIP_TRY(hipMemcpyAsync(m->txt.a[0].x_in, m->emb_pos, (size_t)C * Lt * dt * 4, hipMemcpyDeviceToDevice, s));
+    TRY(launch_set_rows(m->txt.a[0].x_in, C, Lt, dt, 1, n, Pm + m->off[P_CTX], m->tpos + dt, s));
+    for (int i = 0; i < m->txt.layers; ++i) {
+        if (i >= 1 && i - 1 < D1) TRY(launch_set_rows(m->txt.a[i].x_in, C, Lt, dt, 1, n, m->txt_deep + (size_t)(i - 1) * n * dt, nullptr, s));
+        TRY(block_fwd(m, m->txt, i, C, s));
+    }
+    LnFwdArgs lf; lf.x = m->txt.x_last; lf.ldx = dt; lf.row_index = m->eot_rows; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
+    lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = C; lf.d = dt;
+    TRY(launch_ln_fwd(m->dtype, lf, s));
+    TRY(launch_sgemm(false, false, C, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f, e, nullptr, s));
+    // -- cosine logits, trainers/mudpt.py:178-182
+    HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.scale = m->scale; h.logits = m->logits; h.img_n = m->img_n; h.txt_n = m->txt_n;
+    h.img_inv = m->img_inv; h.txt_inv = m->txt_inv; h.B = B; h.C = C; h.e = e;
+    TRY(launch_head_fwd(h, s));
+    return MUDPT_OK;
+}
+
+extern "C" int mudpt_forward(mudpt_model* m, const float* images, int32_t B, float* logits, void* stream) {
+    TRY(ready(m, B, false));
+    ARG_CHECK(images && logits, "forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    TRY(forward_impl(m, images, B, s));
+    HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * m->cfg.n_cls * 4, hipMemcpyDeviceToDevice, s));
+    return MUDPT_OK;
+}
+
+extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const int64_t* labels, int32_t B, float grad_scale,
+                                      float* loss, float* logits, void* stream) {
+    TRY(ready(m, B, true));
+    ARG_CHECK(images && labels && loss, "forward_backward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const mudpt_config& c = m->cfg;
+    const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, C = c.n_cls;
+    const int Lv = m->vis.L, Lt = m->txt.L;
+    float *Pm = m->params, *G = m->grads;
+    TRY(forward_impl(m, images, B, s));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(G, 0, m->total * 4, s));
+
+    // -- head: cross-entropy (mean) + cosine logits backward, trainers/mudpt.py:178-182,250
+    HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.labels = labels; h.scale = m->scale; h.logits = m->logits; h.loss = m->loss; h.dlogits = m->dlogits;
+    h.row_loss = m->row_loss; h.dimg = m->dimg; h.dtxt = m->dtxt; h.img_n = m->img_n; h.txt_n = m->txt_n; h.img_inv = m->img_inv; h.txt_inv = m->txt_inv;
+    h.grad_scale = grad_scale; h.B = B; h.C = C; h.e = e;
+    TRY(launch_head_bwd(h, s));
+    HIP_TRY(hipMemcpyAsync(loss, m->loss, 4, hipMemcpyDeviceToDevice, s));
+
+    // -- vision tower backward
+    Tower& V = m->vis;
+    TRY(launch_sgemm(false, true, B, dv, e, 1.f, m->dimg, e, m->vproj, e, 0.f, m->df_ln, dv, nullptr, s));
+    HIP_TRY(hipMemsetAsync(V.dx, 0, (size_t)B * Lv * dv * 4, s));
+    HIP_TRY(hipMemsetAsync(V.dx_lp, 0, (size_t)B * Lv * dv * 2, s));
+    LnBwdArgs bq; bq.dy = m->df_ln; bq.lddy = dv; bq.dy_f32 = true; bq.x = V.x_last; bq.ldx = dv; bq.row_index = m->cls_rows; bq.mean = m->post_mean; bq.rstd = m->post_rstd;
+    bq.gamma = m->ln_post_g; bq.dx = V.dx; bq.lddx = dv; bq.dx_lp = V.dx_lp; bq.lddx_lp = dv; bq.rows = B; bq.d = dv;
+    TRY(launch_ln_bwd(m->dtype, bq, s));
+    for (int i = V.layers - 1; i >= 0; --i) {
+        TRY(block_bwd(m, V, i, B, s));
+        if (i >= 1 && i - 1 < D1)  // backward of the splice: prompt rows feed d(vis_deep[i-1]); the overwritten rows get no gradient
+            TRY(launch_reduce_rows(m->dtype, V.dx, V.dx_lp, B, Lv, dv, Lv - n, n, m->d_vis_deep + (size_t)(i - 1) * n * dv, true, false, s));
+    }
+    // ln_pre backward on the prompt rows only (patch / CLS rows have no trainable ancestor), in place
+    LnBwdArgs bp; bp.dy = V.dx; bp.lddy = dv; bp.dy_f32 = true; bp.x = m->xpre; bp.ldx = dv; bp.row_index = m->vprompt_rows; bp.mean = m->pre_mean; bp.rstd = m->pre_rstd;
+    bp.gamma = m->ln_pre_g; bp.dx = V.dx; bp.lddx = dv; bp.rows = B * n; bp.d = dv; bp.by_token = true;
+    TRY(launch_ln_bwd(m->dtype, bp, s));
+    TRY(launch_reduce_rows(m->dtype, V.dx, nullptr, B, Lv, dv, Lv - n, n, m->d_vprompt0, false, false, s));
+
+    // -- text tower backward
+    Tower& X = m->txt;
+    TRY(launch_sgemm(false, true, C, dt, e, 1.f, m->dtxt, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s));
+    HIP_TRY(hipMemsetAsync(X.dx, 0, (size_t)C * Lt * dt * 4, s));
+    HIP_TRY(hipMemsetAsync(X.dx_lp, 0, (size_t)C * Lt * dt * 2, s));
+    LnBwdArgs bf; bf.dy = m->dt_ln; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.x_last; bf.ldx = dt; bf.row_index = m->eot_rows; bf.mean = m->fin_mean; bf.rstd = m->fin_rstd;
+    bf.gamma = m->ln_fin_g; bf.dx = X.dx; bf.lddx = dt; bf.dx_lp = X.dx_lp; bf.lddx_lp = dt; bf.rows = C; bf.d = dt;
+    TRY(launch_ln_bwd(m->dtype, bf, s));
+    for (int i = X.layers - 1; i >= 0; --i) {
+        TRY(block_bwd(m, X, i, C, s));
+        if (i >= 1 && i - 1 < D1)
+            TRY(launch_reduce_rows(m->dtype, X.dx, X.dx_lp, C, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, s));
+    }
+    // d ctx (text side): rows 1..n of the first block's input, summed over the class prompts
+    TRY(launch_reduce_rows(m->dtype, X.dx, nullptr, C, Lt, dt, 1, n, G + m->off[P_CTX], false, true, s));
+
+    // -- prompt learner backward (fp32, tiny)
+    // visual_ctx and shared = embed_projection(ctx) both receive d_vprompt0 (clip/model.py:534)
+    TRY(launch_add(G + m->off[P_VCTX], m->d_vprompt0, G + m->off[P_VCTX], (size_t)n * dv, s));
+    TRY(launch_sgemm(true, false, dv, dt, n, 1.f, m->d_vprompt0, dv, Pm + m->off[P_CTX], dt, 1.f, G + m->off[P_EW], dt, nullptr, s));
+    TRY(launch_colsum(m->d_vprompt0, n, dv, dv, G + m->off[P_EB], true, s));
+    TRY(launch_sgemm(false, false, n, dt, dv, 1.f, m->d_vprompt0, dv, Pm + m->off[P_EW], dt, 1.f, G + m->off[P_CTX], dt, nullptr, s));
+    if (D1 > 0) {
+        const int R = D1 * n;
+        // layers >= depth never consume a prompt: rows of d_vis_deep / d_txt_deep beyond the tower depth stay zero
+        const int used_v = (m->vis.layers - 1 < D1 ? m->vis.layers - 1 : D1) * n, used_t = (m->txt.layers - 1 < D1 ? m->txt.layers - 1 : D1) * n;
+        if (used_v < R) HIP_TRY(hipMemsetAsync(m->d_vis_deep + (size_t)used_v * dv, 0, (size_t)(R - used_v) * dv * 4, s));
+        if (used_t < R) HIP_TRY(hipMemsetAsync(m->d_txt_deep + (size_t)used_t * dt, 0, (size_t)(R - used_t) * dt * 4, s));
+        // vis_deep = deep_projections(deep_prompts) + visual_ctx_deep_prompts   (clip/model.py:537, mudpt.py:127)
+        TRY(launch_add(G + m->off[P_VDEEP], m->d_vis_deep, G + m->off[P_VDEEP], (size_t)R * dv, s));
+        TRY(launch_sgemm(true, false, dv, dt, R, 1.f, m->d_vis_deep, dv, Pm + m->off[P_DEEP], dt, 1.f, G + m->off[P_DW], dt, nullptr, s));
+        TRY(launch_colsum(m->d_vis_deep, R, dv, dv, G + m->off[P_DB], true, s));
+        TRY(launch_sgemm(false, false, R, dt, dv, 1.f, m->d_vis_deep, dv, Pm + m->off[P_DW], dt, 1.f, G + m->off[P_DEEP], dt, nullptr, s));
+        // txt_deep = deep_prompts + visual_ctx_deep_projections(visual_ctx_deep_prompts)   (mudpt.py:175, clip/model.py:539)
+        TRY(launch_add(G + m->off[P_DEEP], m->d_txt_deep, G + m->off[P_DEEP], (size_t)R * dt, s));
+        TRY(launch_sgemm(true, false, e, dv, R, 1.f, m->d_txt_deep, e, Pm + m->off[P_VDEEP], dv, 1.f, G + m->off[P_VW], dv, nullptr, s));
+        TRY(launch_colsum(m->d_txt_deep, R, e, e, G + m->off[P_VB], true, s));
+        TRY(launch_sgemm(false, false, R, dv, e, 1.f, m->d_txt_deep, e, Pm + m->off[P_VW], dv, 1.f, G + m->off[P_VDEEP], dv, nullptr, s));
+    }
+    return MUDPT_OK;
+}
+
+extern "C" int mudpt_sgd_step(mudpt_model* m, float lr, float momentum, float wd, float dampening, int32_t nesterov, void* stream) {
+    ARG_CHECK(m && m->params && m->grads, "sgd_step: parameters / gradients not bound");
+    TRY(launch_sgd(m->params, m->grads, m->momentum, m->total, lr, momentum, wd, dampening, nesterov != 0, m->sgd_first, (hipStream_t)stream));
+    m->sgd_first = false;
+    return MUDPT_OK;
+}
+extern "C" int mudpt_sgd_reset(mudpt_model* m) {
+    ARG_CHECK(m, "sgd_reset: null model");
+    m->sgd_first = true;
+    return MUDPT_OK;
+}
+
+extern "C" int mudpt_profile_enable(mudpt_model* m, int32_t enable) {
+    ARG_CHECK(m, "profile_enable: null model");
+    m->prof = enable != 0;
+    m->ev_used = 0;
+    m->ev_flop.clear();
+    return MUDPT_OK;
+}
+// Synchronises the device; sums over the GEMM launches recorded since the last enable / read.
+extern "C" int mudpt_profile_read(mudpt_model* m, double* gemm_ms, double* gemm_flop, int64_t* launches) {
+    ARG_CHECK(m && gemm_ms && gemm_flop && launches, "profile_read: null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    double ms = 0, fl = 0;
+    for (size_t i = 0; i < m->ev_used; i += 2) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, m->ev[i], m->ev[i + 1]));
+        ms += t;
+        fl += m->ev_flop[i / 2];
+    }
+    *gemm_ms = ms; *gemm_flop = fl; *launches = (int64_t)(m->ev_used / 2);
+    m->ev_used = 0;
+    m->ev_flop.clear();
+    return MUDPT_OK;
+}
+
+// Copy an internal fp32 activation of the LAST call to the host (synchronises the device): per-block parity tests.
+// names: "vis.x_in.<i>", "vis.x_out", "txt.x_in.<i>", "txt.x_out", "image_features", "text_features"
+extern "C" int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* host_out, size_t capacity, size_t* numel) {
+    ARG_CHECK(m && name && numel, "debug_read: null argument");
+    const std::string k(name);
+    const mudpt_config& c = m->cfg;
+    const float* src = nullptr;
+    size_t n = 0;
+    auto tower = [&](Tower& t, const std::string& rest, int nseq) {
+        n = (size_t)nseq * t.L * t.d;
+        if (rest == "x_out") src = t.x_last;
+        else if (rest.rfind("x_in.", 0) == 0) {
+            const int i = atoi(rest.c_str() + 5);
+            if (i >= 0 && i < t.layers) src = t.a[i].x_in;
+        }
+    };
+    ARG_CHECK(batch > 0 && batch <= c.max_batch, "debug_read: bad batch %d", batch);
+    if (k.rfind("vis.", 0) == 0) tower(m->vis, k.substr(4), batch);
+    else if (k.rfind("txt.", 0) == 0) tower(m->txt, k.substr(4), c.n_cls);
+    else if (k == "image_features") { src = m->img_f; n = (size_t)batch * c.embed_dim; }
+    else if (k == "text_features") { src = m->txt_f; n = (size_t)c.n_cls * c.embed_dim; }
+    ARG_CHECK(src, "debug_read: unknown tensor '%s'", name);
+    *numel = n;
+    if (!host_out) return MUDPT_OK;
+    ARG_CHECK(capacity >= n, "debug_read: capacity %zu < %zu", capacity, n);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, src, n * 4, hipMemcpyDeviceToHost));
+    return MUDPT_OK;
+}
+
+// ---- single kernels ---------------------------------------------------------------------------------------------
+extern "C" int mudpt_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
+                          const float* bias, void* out0, int32_t ldo0, void* out1, int32_t ldo1, const void* aux, int32_t ldaux, int32_t patches,
+                          int32_t seq_len, const float* pos, void* stream) {
+    GemmArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias; a.out0 = out0; a.ldo0 = ldo0; a.out1 = out1; a.ldo1 = ldo1;
+    a.aux = aux; a.ldaux = ldaux; a.patches = patches; a.seq_len = seq_len; a.pos = pos;
+    return launch_gemm(dtype, epi, a, (hipStream_t)stream);
+}
+extern "C" int mudpt_layernorm_fwd(int32_t dtype, const float* x, int32_t ldx, const int32_t* row_index, const float* gamma, const float* beta, void* out,
+                                   int32_t ldo, int32_t out_f32, float* mean, float* rstd, int32_t rows, int32_t d, void* stream) {
+    LnFwdArgs a; a.x = x; a.ldx = ldx; a.row_index = row_index; a.gamma = gamma; a.beta = beta; a.out = out; a.ldo = ldo; a.out_f32 = out_f32 != 0;
+    a.mean = mean; a.rstd = rstd; a.rows = rows; a.d = d;
+    return launch_ln_fwd(dtype, a, (hipStream_t)stream);
+}
+extern "C" int mudpt_layernorm_bwd(int32_t dtype, const void* dy, int32_t lddy, int32_t dy_f32, const float* x, int32_t ldx, const int32_t* row_index,
+                                   const float* mean, const float* rstd, const float* gamma, const float* dres, int32_t lddres, float* dx, int32_t lddx,
+                                   void* dx_lp, int32_t lddx_lp, int32_t rows, int32_t d, void* stream) {
+    LnBwdArgs a; a.dy = dy; a.lddy = lddy; a.dy_f32 = dy_f32 != 0; a.x = x; a.ldx = ldx; a.row_index = row_index; a.mean = mean; a.rstd = rstd; a.gamma = gamma;
+    a.dres = dres; a.lddres = lddres; a.dx = dx; a.lddx = lddx; a.dx_lp = dx_lp; a.lddx_lp = lddx_lp; a.rows = rows; a.d = d;
+    return launch_ln_bwd(dtype, a, (hipStream_t)stream);
+}
+extern "C" int mudpt_attention_padded_len(int32_t L) { return attn_padded_len(L); }
+extern "C" int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream) {
+    AttnArgs a; a.qkv = qkv; a.out = out; a.lse = lse; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;
+    return launch_attn_fwd(dtype, a, (hipStream_t)stream);
+}
+extern "C" int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int32_t B,
+                                   int32_t L, int32_t H, int32_t causal, void* stream) {
+    AttnArgs a; a.qkv = qkv; a.out = (void*)out; a.dout = dout; a.lse = (float*)lse; a.delta = delta; a.dqkv = dqkv; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;
+    return launch_attn_bwd(dtype, a, (hipStream_t)stream);
+}

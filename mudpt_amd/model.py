@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's ``CustomCLIP`` (trainers/mudpt.py:159-184) over libmudpt_hip.so.
+
+``CustomCLIP`` here is an ``nn.Module`` whose ONLY tensors are the 10 trainable ones, registered under the
+reference's state-dict names (``mudpt_prompt_learner.ctx`` ... ``image_encoder.visual_ctx_deep_projections.bias``,
+trainers/mudpt.py:205-218) as views of one flat fp32 bucket, so a torch / Dassl optimizer, ``state_dict()``
+and the reference's ``load_model`` (``strict=False``) work unchanged.  The frozen CLIP weights live inside
+the library in its own HBM layout.  torch supplies device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import capi
+
+
+@dataclass(frozen=True)
+class ModelShape:
+    """Dimensions the reference infers from the checkpoint (clip/model.py:885-904) plus the prompt config."""
+    image_size: int = 224
+    patch: int = 16
+    v_width: int = 768
+    v_layers: int = 12
+    v_heads: int = 12
+    t_width: int = 512
+    t_layers: int = 12
+    t_heads: int = 8
+    ctx_len: int = 77
+    embed_dim: int = 512
+    n_ctx: int = 4
+    depth: int = 12
+
+    @staticmethod
+    def from_state_dict(sd: Dict[str, torch.Tensor], n_ctx: int, depth: int) -> "ModelShape":
+        """Same inference rules as clip/model.py:881-904 build_model (ViT branch)."""
+        v_width = sd["visual.conv1.weight"].shape[0]
+        v_layers = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+        patch = sd["visual.conv1.weight"].shape[-1]
+        grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+        t_width = sd["ln_final.weight"].shape[0]
+        t_layers = len(set(k.split(".")[2] for k in sd if k.startswith("transformer.resblocks")))
+        return ModelShape(image_size=patch * grid, patch=patch, v_width=v_width, v_layers=v_layers, v_heads=v_width // 64,
+                          t_width=t_width, t_layers=t_layers, t_heads=t_width // 64,
+                          ctx_len=sd["positional_embedding"].shape[0], embed_dim=sd["text_projection"].shape[1],
+                          n_ctx=n_ctx, depth=depth)
+
+
+class _Holder(nn.Module):
+    """Namespace module so parameters get the reference's dotted state-dict keys."""
+
+
+class CustomCLIP(nn.Module):
+    def __init__(self, shape: ModelShape, clip_state: Dict[str, torch.Tensor], tokenized_prompts: torch.Tensor,
+                 ctx_token_ids: Optional[Sequence[int]] = None, max_batch: int = 256, dtype: str = "bf16",
+                 device: str = "cuda:0", seed: Optional[int] = None):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise capi.MudptError("mudpt_amd needs an MI355X (HIP device); there is no CPU path in the product")
+        self.lib = capi.load()
+        self.shape = shape
+        self.device = torch.device(device)
+        self.dtype_name = dtype
+        self.n_cls = int(tokenized_prompts.shape[0])
+        self.max_batch = int(max_batch)
+        self.tokenized_prompts = tokenized_prompts.clone()
+        cfg = capi.Config(shape.image_size, shape.patch, shape.v_width, shape.v_layers, shape.v_heads, shape.t_width,
+                          shape.t_layers, shape.t_heads, shape.ctx_len, shape.embed_dim, shape.n_ctx, shape.depth,
+                          self.n_cls, self.max_batch, {"bf16": capi.BF16, "fp16": capi.F16}[dtype])
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        capi.check(self.lib.mudpt_create(C.byref(cfg), C.byref(h)), "create")
+        self._h = h
+        # frozen weights, by OpenAI CLIP key (clip/model.py:919 load_state_dict)
+        for k, v in clip_state.items():
+            if k == "token_embedding.weight" or not isinstance(v, torch.Tensor):
+                continue
+            t = v.detach().to("cpu", torch.float32).contiguous()
+            capi.check(self.lib.mudpt_set_weight(h, k.encode(), capi.ptr(t), t.numel()), f"set_weight({k})")
+        # class prompts: token_embedding(tokenized) and the EOT position (trainers/mudpt.py:85-90,154)
+        emb_w = clip_state["token_embedding.weight"].detach().to("cpu", torch.float32)
+        tok = tokenized_prompts.to("cpu").long()
+        emb = emb_w[tok].contiguous()
+        eot = tok.argmax(dim=-1).to(torch.int32).contiguous()
+        capi.check(self.lib.mudpt_set_class_prompts(h, capi.ptr(emb), capi.ptr(eot)), "set_class_prompts")
+        # the flat parameter / gradient buckets and the 10 named views
+        total = self.lib.mudpt_param_numel(h)
+        self.flat_params = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.flat_grads = torch.zeros(total, dtype=torch.float32, device=self.device)
+        capi.check(self.lib.mudpt_bind_params(h, capi.ptr(self.flat_params), capi.ptr(self.flat_grads)), "bind_params")
+        self.mudpt_prompt_learner = _Holder()
+        self.mudpt_prompt_learner.embed_projection = _Holder()
+        self.mudpt_prompt_learner.deep_projections = _Holder()
+        self.image_encoder = _Holder()
+        self.image_encoder.visual_ctx_deep_projections = _Holder()
+        self.param_names = []
+        for i in range(self.lib.mudpt_param_count(h)):
+            name, off, numel, ndim, shp = C.c_char_p(), C.c_size_t(), C.c_size_t(), C.c_int32(), (C.c_int64 * 3)()
+            capi.check(self.lib.mudpt_param_info(h, i, C.byref(name), C.byref(off), C.byref(numel), C.byref(ndim), C.byref(shp)))
+            key = name.value.decode()
+            view = self.flat_params[off.value:off.value + numel.value].view(*[int(shp[j]) for j in range(ndim.value)])
+            p = nn.Parameter(view, requires_grad=True)
+            p.grad = self.flat_grads[off.value:off.value + numel.value].view_as(view)
+            mod = self
+            *path, leaf = key.split(".")
+            for part in path:
+                mod = getattr(mod, part)
+            mod.register_parameter(leaf, p)
+            self.param_names.append(key)
+        self._init_trainables(emb_w, ctx_token_ids, seed)
+        self._loss = torch.zeros(4, dtype=torch.float32, device=self.device)
+
+    # -- initialisation of the trainables, trainers/mudpt.py:57-81 and clip/model.py:512-519 ---------------------
+    def _init_trainables(self, emb_w, ctx_token_ids, seed):
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        sd = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, p in sd.items():
+                if k.endswith(".weight") or k.endswith(".bias"):
+                    fan_in = sd[k.rsplit(".", 1)[0] + ".weight"].shape[1]
+                    v = (torch.rand(p.shape, generator=g) * 2 - 1) / math.sqrt(fan_in)  # nn.Linear default
+                else:
+                    v = 0.02 * torch.randn(p.shape, generator=g)  # nn.init.normal_(std=0.02)
+                p.copy_(v)
+            if ctx_token_ids is not None:  # CTX_INIT words -> their token embeddings
+                sd["mudpt_prompt_learner.ctx"].copy_(emb_w[list(ctx_token_ids)])
+
+    def set_params(self, tensors: Dict[str, torch.Tensor]):
+        with torch.no_grad():
+            for k, p in self.named_parameters():
+                if k in tensors:
+                    p.copy_(tensors[k])
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        return {k: p.grad for k, p in self.named_parameters()}
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- trainers/mudpt.py:170-184 ---------------------------------------------------------------------------------
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        image = image.to(self.device, torch.float32).contiguous()
+        B = image.shape[0]
+        logits = torch.empty(B, self.n_cls, dtype=torch.float32, device=self.device)
+        capi.check(self.lib.mudpt_forward(self._h, capi.ptr(image), B, capi.ptr(logits), self._stream()), "forward")
+        return logits
+
+    # -- trainers/mudpt.py:249-251 minus the optimizer step: loss (device scalar) + .grad of the 10 tensors ---------------
+    def forward_backward(self, image: torch.Tensor, label: torch.Tensor, grad_scale: float = 1.0,
+                         return_logits: bool = False):
+        image = image.to(self.device, torch.float32).contiguous()
+        label = label.to(self.device, torch.int64).contiguous()
+        B = image.shape[0]
+        logits = torch.empty(B, self.n_cls, dtype=torch.float32, device=self.device) if return_logits else None
+        capi.check(self.lib.mudpt_forward_backward(self._h, capi.ptr(image), capi.ptr(label), B, grad_scale,
+                                                   capi.ptr(self._loss), capi.ptr(logits), self._stream()), "forward_backward")
+        return (self._loss[0], logits) if return_logits else self._loss[0]
+
+    def sgd_step(self, lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, dampening: float = 0.0, nesterov: bool = False):
+        capi.check(self.lib.mudpt_sgd_step(self._h, lr, momentum, weight_decay, dampening, int(nesterov), self._stream()), "sgd_step")
+
+    def profile(self, enable: bool):
+        capi.check(self.lib.mudpt_profile_enable(self._h, int(enable)), "profile_enable")
+
+    def profile_read(self):
+        """(summed GEMM ms, summed algorithmic GEMM FLOPs, launches) since the last enable / read."""
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        capi.check(self.lib.mudpt_profile_read(self._h, C.byref(ms), C.byref(fl), C.byref(n)), "profile_read")
+        return ms.value, fl.value, n.value
+
+    def debug_read(self, name: str, batch: int) -> torch.Tensor:
+        """Flat fp32 host copy of an internal activation of the last call (test hook, see include/mudpt.h)."""
+        n = C.c_size_t()
+        capi.check(self.lib.mudpt_debug_read(self._h, name.encode(), batch, None, 0, C.byref(n)), "debug_read")
+        out = torch.empty(n.value, dtype=torch.float32)
+        capi.check(self.lib.mudpt_debug_read(self._h, name.encode(), batch, capi.ptr(out), n.value, C.byref(n)), "debug_read")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            torch.cuda.synchronize(self.device)
+            self.lib.mudpt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

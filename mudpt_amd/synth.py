@@ -1,0 +1,80 @@
+"""Synthetic stand-ins for what needs the network in the reference: a random-initialised CLIP state dict
+(no ViT-B-16.pt offline; clip/clip.py:31-41 are download URLs) and class prompts without the BPE vocabulary.
+
+Used by bench.py and the Dassl-free harness only; real runs pass a checkpoint's state dict instead."""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from .model import ModelShape
+
+# first Caltech-101 class names (datasets/caltech101.py:8-14 renaming applied), the benchmark's 11 classes
+BENCH_CLASSNAMES = ["face", "leopard", "motorbike", "accordion", "airplane", "anchor", "ant", "barrel", "bass", "beaver",
+                    "binocular"]
+# clip.tokenize("a photo of a <name>.") for the names above (clip/clip.py:199-239): SOT 49406, "a photo of a"
+# = 320 1125 539 320, name, "." = 269, EOT 49407.  Values recorded from the reference tokenizer (tests/golden).
+_BENCH_NAME_TOKENS = [[1710], [15931], [33341], [48760], [16451], [13201], [773], [11703], [5992], [22874], [29172, 10940]]
+CTX_INIT_TOKENS = [320, 1125, 539, 320]  # "a photo of a"
+VOCAB = 49408
+
+
+def bench_tokenized_prompts(ctx_len: int = 77) -> torch.Tensor:
+    tok = torch.zeros(len(_BENCH_NAME_TOKENS), ctx_len, dtype=torch.int32)
+    for i, name in enumerate(_BENCH_NAME_TOKENS):
+        ids = [49406] + CTX_INIT_TOKENS + name + [269, 49407]
+        tok[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+    return tok
+
+
+def synthetic_tokenized_prompts(n_cls: int, n_ctx: int = 4, ctx_len: int = 77, seed: int = 7) -> torch.Tensor:
+    """Prompts shaped like "<ctx words> <1-3 name tokens> ." for synthetic class lists (e.g. 1000 ImageNet-sized)."""
+    g = torch.Generator().manual_seed(seed)
+    tok = torch.zeros(n_cls, ctx_len, dtype=torch.int32)
+    for c in range(n_cls):
+        k = 1 + int(torch.randint(0, 3, (1,), generator=g))
+        ids = [49406] + (CTX_INIT_TOKENS * n_ctx)[:n_ctx] + [int(v) for v in torch.randint(1000, 48000, (k,), generator=g)] + [269, 49407]
+        tok[c, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+    return tok
+
+
+def random_clip_state(shape: ModelShape, seed: int = 0, fp16_weights: bool = True) -> Dict[str, torch.Tensor]:
+    """Random CLIP weights with the distributions of CLIP.initialize_parameters (clip/model.py:781-808) and the
+    vision tower's width^-1/2 scale (clip/model.py:506-508,524); random, not zeros (zeros inflate clocks)."""
+    g = torch.Generator().manual_seed(seed)
+    dv, dt, e = shape.v_width, shape.t_width, shape.embed_dim
+    P = (shape.image_size // shape.patch) ** 2
+
+    def rn(*s, std=1.0):
+        t = torch.randn(*s, generator=g) * std
+        return t.half().float() if fp16_weights else t
+
+    sd = {
+        "visual.conv1.weight": rn(dv, 3, shape.patch, shape.patch, std=(3 * shape.patch ** 2) ** -0.5),
+        "visual.class_embedding": rn(dv, std=dv ** -0.5),
+        "visual.positional_embedding": rn(P + 1, dv, std=dv ** -0.5),
+        "visual.ln_pre.weight": torch.ones(dv), "visual.ln_pre.bias": torch.zeros(dv),
+        "visual.ln_post.weight": torch.ones(dv), "visual.ln_post.bias": torch.zeros(dv),
+        "visual.proj": rn(dv, e, std=dv ** -0.5),
+        "token_embedding.weight": rn(VOCAB, dt, std=0.02),
+        "positional_embedding": rn(shape.ctx_len, dt, std=0.01),
+        "ln_final.weight": torch.ones(dt), "ln_final.bias": torch.zeros(dt),
+        "text_projection": rn(dt, e, std=dt ** -0.5),
+        "logit_scale": torch.tensor(math.log(1 / 0.07)),
+    }
+    for prefix, d, layers in (("visual.transformer", dv, shape.v_layers), ("transformer", dt, shape.t_layers)):
+        for i in range(layers):
+            p = f"{prefix}.resblocks.{i}."
+            sd[p + "ln_1.weight"], sd[p + "ln_1.bias"] = torch.ones(d), torch.zeros(d)
+            sd[p + "ln_2.weight"], sd[p + "ln_2.bias"] = torch.ones(d), torch.zeros(d)
+            sd[p + "attn.in_proj_weight"] = rn(3 * d, d, std=d ** -0.5)
+            sd[p + "attn.in_proj_bias"] = torch.zeros(3 * d)
+            sd[p + "attn.out_proj.weight"] = rn(d, d, std=d ** -0.5 * (2 * layers) ** -0.5)
+            sd[p + "attn.out_proj.bias"] = torch.zeros(d)
+            sd[p + "mlp.c_fc.weight"] = rn(4 * d, d, std=(2 * d) ** -0.5)
+            sd[p + "mlp.c_fc.bias"] = rn(4 * d, std=0.02)
+            sd[p + "mlp.c_proj.weight"] = rn(d, 4 * d, std=d ** -0.5 * (2 * layers) ** -0.5)
+            sd[p + "mlp.c_proj.bias"] = rn(d, std=0.02)
+    return sd

@@ -1,0 +1,223 @@
+"""GPU parity of the single HIP kernels against the CPU oracle, called through the C ABI (ctypes)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import mudpt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DT = {"bf16": (0, torch.bfloat16), "fp16": (1, torch.float16)}
+EPS = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}  # half ulp relative
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mudpt_amd import capi
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return capi.load()
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ok(lib, rc):
+    assert rc == 0, lib.mudpt_last_error().decode()
+
+
+def gemm(lib, dt, epi, A, B, bias=None, out0=None, out1=None, aux=None, patches=0, seq_len=0, pos=None):
+    M, K = A.shape
+    N = B.shape[0]
+    ok(lib, lib.mudpt_gemm(dt, epi, M, N, K, P(A), A.stride(0), P(B), B.stride(0), P(bias), P(out0), out0.stride(0),
+                           P(out1), out1.stride(0) if out1 is not None else 0, P(aux), aux.stride(0) if aux is not None else 0,
+                           patches, seq_len, P(pos), None))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gemm_exact_integers(lib, dtype):
+    """Small-integer operands: every product and sum is exact in fp32, so the result must be bit-exact.
+    A is a shifted identity-like pattern and B is asymmetric, which catches swapped row/col maps."""
+    dt, tt = DT[dtype]
+    M, N, K = 200, 144, 128
+    g = torch.Generator().manual_seed(0)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = (torch.arange(N).view(N, 1) % 5 - 2 + (torch.arange(K).view(1, K) % 3)).float()  # asymmetric
+    ref = A @ B.t()
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    gemm(lib, dt, 5, A.cuda().to(tt), B.cuda().to(tt), out0=out)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(804, 2304, 768), (847, 512, 2048), (77, 128, 64), (4096, 768, 3072), (33000, 768, 768)])
+def test_gemm_epilogues(lib, dtype, shape):
+    dt, tt = DT[dtype]
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(tt)
+    B = (torch.randn(N, K, generator=g) * K ** -0.5).to(tt)
+    bias = torch.randn(N, generator=g)
+    acc = A.double() @ B.double().t()
+    Ad, Bd, bd = A.cuda(), B.cuda(), bias.cuda()
+    tol = dict(atol=4 * EPS[dtype], rtol=4 * EPS[dtype])
+    # 0: store T with bias
+    out = torch.empty(M, N, device="cuda", dtype=tt)
+    gemm(lib, dt, 0, Ad, Bd, bias=bd, out0=out)
+    torch.testing.assert_close(out.cpu().double(), acc + bias.double(), **tol)
+    # 5: fp32 store, no bias
+    o32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    gemm(lib, dt, 5, Ad, Bd, out0=o32)
+    torch.testing.assert_close(o32.cpu().double(), acc, atol=2e-5 * K ** 0.5, rtol=1e-5)
+    # 1: bias + QuickGELU, both outputs
+    u, gl = torch.empty(M, N, device="cuda", dtype=tt), torch.empty(M, N, device="cuda", dtype=tt)
+    gemm(lib, dt, 1, Ad, Bd, bias=bd, out0=u, out1=gl)
+    uref = acc + bias.double()
+    torch.testing.assert_close(u.cpu().double(), uref, **tol)
+    torch.testing.assert_close(gl.cpu().double(), uref * torch.sigmoid(1.702 * uref), **tol)
+    # 2: residual fp32
+    res = torch.randn(M, N, generator=g)
+    gemm(lib, dt, 2, Ad, Bd, bias=bd, out0=o32, aux=res.cuda())
+    torch.testing.assert_close(o32.cpu().double(), res.double() + uref, atol=2e-5 * K ** 0.5, rtol=1e-5)
+    # 3: QuickGELU backward
+    upre = torch.randn(M, N, generator=g).to(tt)
+    gemm(lib, dt, 3, Ad, Bd, out0=out, aux=upre.cuda())
+    ud = upre.double()
+    s = torch.sigmoid(1.702 * ud)
+    torch.testing.assert_close(out.cpu().double(), acc * (s * (1 + 1.702 * ud * (1 - s))), **tol)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gemm_patch_epilogue(lib, dtype):
+    """Patch-embed GEMM: row m of the im2col matrix lands on token row (m / P) * L + 1 + m % P, plus pos-emb."""
+    dt, tt = DT[dtype]
+    Bn, Pn, L, N, K = 3, 4, 7, 192, 768
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(Bn * Pn, K, generator=g).to(tt)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(tt)
+    pos = torch.randn(1 + Pn, N, generator=g)
+    out = torch.full((Bn * L, N), 7.0, device="cuda")
+    gemm(lib, dt, 4, A.cuda(), W.cuda(), out0=out, patches=Pn, seq_len=L, pos=pos.cuda())
+    ref = torch.full((Bn, L, N), 7.0, dtype=torch.float64)
+    ref[:, 1:1 + Pn] = (A.double() @ W.double().t()).view(Bn, Pn, N) + pos[1:].double()
+    torch.testing.assert_close(out.cpu().double().view(Bn, L, N), ref, atol=1e-4, rtol=1e-5)
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    A = torch.zeros(64, 96, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
+    rc = lib.mudpt_gemm(0, 0, 64, 64, 96, P(A), 96, P(A), 96, None, P(out), 64, None, 0, None, 0, 0, 0, None, None)
+    assert rc == 1 and b"multiple of 64" in lib.mudpt_last_error()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("rows,d", [(804, 768), (847, 512), (21, 192), (5, 128), (4, 1024)])
+def test_layernorm_fwd_bwd(lib, dtype, rows, d):
+    dt, tt = DT[dtype]
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, d, generator=g) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = O.layer_norm(xr, gamma, beta)
+    out = torch.empty(rows, d, device="cuda", dtype=tt)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    xc, gc, bc = x.cuda(), gamma.cuda(), beta.cuda()  # keep device tensors alive across the async launches
+    ok(lib, lib.mudpt_layernorm_fwd(dt, P(xc), d, None, P(gc), P(bc), P(out), d, 0, P(mean), P(rstd), rows, d, None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu().float(), y.detach(), atol=4 * EPS[dtype], rtol=4 * EPS[dtype])
+    o32 = torch.empty(rows, d, device="cuda")
+    ok(lib, lib.mudpt_layernorm_fwd(dt, P(xc), d, None, P(gc), P(bc), P(o32), d, 1, None, None, rows, d, None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(o32.cpu(), y.detach(), atol=2e-5, rtol=1e-5)
+    # backward: dx = dres + LN'(dy), dy in T
+    dy = torch.randn(rows, d, generator=g).to(tt)
+    dres = torch.randn(rows, d, generator=g)
+    (dx_ref,) = torch.autograd.grad(y, xr, dy.float())
+    dx = torch.empty(rows, d, device="cuda")
+    dx_lp = torch.empty(rows, d, device="cuda", dtype=tt)
+    dyc, drc = dy.cuda(), dres.cuda()
+    ok(lib, lib.mudpt_layernorm_bwd(dt, P(dyc), d, 0, P(xc), d, None, P(mean), P(rstd), P(gc), P(drc), d, P(dx), d,
+                                    P(dx_lp), d, rows, d, None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dx.cpu(), dx_ref + dres, atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(dx_lp.cpu().float(), dx_ref + dres, atol=4 * EPS[dtype] * 4, rtol=4 * EPS[dtype])
+
+
+def test_layernorm_gather_scatter(lib):
+    """row_index: LN of selected token rows (ln_post on CLS rows, ln_final on EOT rows) and the scatter of its gradient."""
+    rows, d, total = 6, 256, 40
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(total, d, generator=g)
+    idx = torch.tensor([0, 7, 14, 21, 28, 39], dtype=torch.int32)
+    gamma, beta = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    xr = x[idx.long()].clone().requires_grad_(True)
+    y = O.layer_norm(xr, gamma, beta)
+    out, mean, rstd = torch.empty(rows, d, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    xc, ic, gc, bc = x.cuda(), idx.cuda(), gamma.cuda(), beta.cuda()
+    ok(lib, lib.mudpt_layernorm_fwd(0, P(xc), d, P(ic), P(gc), P(bc), P(out), d, 1, P(mean), P(rstd), rows, d, None))
+    dy = torch.randn(rows, d, generator=g)
+    (dref,) = torch.autograd.grad(y, xr, dy)
+    dx = torch.zeros(total, d, device="cuda")
+    dyc = dy.cuda()
+    ok(lib, lib.mudpt_layernorm_bwd(0, P(dyc), d, 1, P(xc), d, P(ic), P(mean), P(rstd), P(gc), None, 0, P(dx), d, None, 0, rows, d, None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu(), y.detach(), atol=2e-5, rtol=1e-5)
+    full = torch.zeros(total, d)
+    full[idx.long()] = dref
+    torch.testing.assert_close(dx.cpu(), full, atol=2e-5, rtol=2e-5)
+
+
+ATTN_CASES = [(3, 201, 12, False), (11, 77, 8, True), (2, 7, 3, False), (2, 33, 2, True), (1, 224, 1, False), (2, 64, 2, True)]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,L,H,causal", ATTN_CASES)
+def test_attention_fwd_bwd(lib, dtype, B, L, H, causal):
+    dt, tt = DT[dtype]
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    qkv = torch.randn(B, L, 3 * H * 64, generator=g).to(tt)
+    dout = torch.randn(B, L, H * 64, generator=g).to(tt)
+    q32 = qkv.float().requires_grad_(True)
+    ref = O.attention(q32, H, O.causal_mask(L) if causal else None)
+    (dref,) = torch.autograd.grad(ref, q32, dout.float())
+    Lp = lib.mudpt_attention_padded_len(L)
+    assert Lp % 32 == 0 and Lp >= L
+    qc = qkv.cuda()
+    out = torch.empty(B, L, H * 64, device="cuda", dtype=tt)
+    lse = torch.empty(B, H, Lp, device="cuda")
+    ok(lib, lib.mudpt_attention_fwd(dt, P(qc), P(out), P(lse), B, L, H, int(causal), None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu().float(), ref.detach(), atol=6 * EPS[dtype], rtol=6 * EPS[dtype])
+    # LSE against the definition
+    q, k, _ = q32.detach().split(H * 64, dim=-1)
+    s = (q.view(B, L, H, 64).transpose(1, 2) @ k.view(B, L, H, 64).transpose(1, 2).transpose(-1, -2)) / 8
+    if causal:
+        s = s + O.causal_mask(L)
+    torch.testing.assert_close(lse.cpu()[:, :, :L], torch.logsumexp(s, dim=-1), atol=1e-3, rtol=1e-4)
+    dqkv = torch.zeros(B, L, 3 * H * 64, device="cuda", dtype=tt)
+    delta = torch.empty(B, H, Lp, device="cuda")
+    doc = dout.cuda()
+    ok(lib, lib.mudpt_attention_bwd(dt, P(qc), P(out), P(doc), P(lse), P(delta), P(dqkv), B, L, H, int(causal), None))
+    torch.cuda.synchronize()
+    scale = dref.abs().max().item()
+    torch.testing.assert_close(dqkv.cpu().float(), dref, atol=12 * EPS[dtype] * scale, rtol=8 * EPS[dtype])
+
+
+def test_attention_softmax_extremes(lib):
+    """Large score spread: one key dominates a row (exp underflow for the rest) -- no NaN, matches the oracle."""
+    B, L, H = 1, 201, 1
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B, L, 192, generator=g)
+    qkv[0, 5, :64] *= 30  # query 5: huge logits
+    qkv[0, 17, 64:128] *= 30  # key 17: huge against every query
+    qkv = qkv.to(torch.float16)
+    ref = O.attention(qkv.float(), H, None)
+    out = torch.empty(B, L, 64, device="cuda", dtype=torch.float16)
+    lse = torch.empty(B, H, 224, device="cuda")
+    qc = qkv.cuda()
+    ok(lib, lib.mudpt_attention_fwd(1, P(qc), P(out), P(lse), B, L, H, 0, None))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(lse[:, :, :L]).all()
+    torch.testing.assert_close(out.cpu().float(), ref, atol=4e-3, rtol=4e-3)
