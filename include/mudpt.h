@@ -84,6 +84,11 @@ int mudpt_forward(mudpt_model* m, const float* images_dev, int32_t batch, float*
 int mudpt_forward_backward(mudpt_model* m, const float* images_dev, const int64_t* labels_dev, int32_t batch,
                            float grad_scale, float* loss_dev, float* logits_dev, void* stream);
 
+/* Static loss scale of the backward pass (default 128): per-sample logit gradients are multiplied by it so the
+ * fp16 copies of the token gradients stay normal; the gradients written to the bucket are unscaled again.
+ * The reference's analogue is GradScaler under PREC == "amp" (trainers/mudpt.py:228,243-246). */
+int mudpt_set_loss_scale(mudpt_model* m, float loss_scale);
+
 /* torch.optim.SGD update of the bound parameters from the bound gradients (momentum buffer library-owned). */
 int mudpt_sgd_step(mudpt_model* m, float lr, float momentum, float weight_decay, float dampening,
                    int32_t nesterov, void* stream);

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mudpt_sgd_step": (_i32, [_vp, _f32, _f32, _f32, _f32, _i32, _vp]),
     "mudpt_sgd_reset": (_i32, [_vp]),
     "mudpt_debug_read": (_i32, [_vp, C.c_char_p, _i32, _vp, _sz, C.POINTER(_sz)]),
+    "mudpt_set_loss_scale": (_i32, [_vp, _f32]),
     "mudpt_profile_enable": (_i32, [_vp, _i32]),
     "mudpt_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mudpt_gemm": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32,
@@ -72,6 +73,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MudptError(f"{LIB_PATH} is missing: run `python -m mudpt_amd.build` (hipcc, gfx950) first; "
                          "there is no CPU fallback for the MuDPT path")
+    # torch ships its own libamdhip64; importing it first makes the library bind to that same HIP runtime
+    # instance (same SONAME), which it must share with torch's allocator and streams.  Loaded the other way
+    # round the process ends up with two runtimes and the library sees "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

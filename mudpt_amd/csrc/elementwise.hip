@@ -60,7 +60,8 @@ int launch_set_rows(float* x, int B, int L, int d, int row0, int n, const float*
 // ---- reduce_rows: out[i, c] (+)= sum_b src[b, row0 + i, c] (b ascending: bitwise reproducible); optional zeroing
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(float* __restrict__ src, typename T::elem* __restrict__ src_lp, int B, int L, int d,
-                                                          int row0, int n, float* __restrict__ out, bool zero_src, bool accumulate) {
+                                                          int row0, int n, float* __restrict__ out, bool zero_src, bool accumulate,
+                                                          float scale) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * d) return;
     const int i = idx / d, c = idx % d;
@@ -73,17 +74,18 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(float* __restrict__ sr
             if (src_lp) src_lp[o] = (typename T::elem)0.f;
         }
     }
+    acc *= scale;
     out[idx] = accumulate ? out[idx] + acc : acc;
 }
 
 int launch_reduce_rows(int dtype, float* src, void* src_lp, int B, int L, int d, int row0, int n, float* out, bool zero_src,
-                       bool accumulate, hipStream_t s) {
+                       bool accumulate, float scale, hipStream_t s) {
     ARG_CHECK(src && out && B > 0 && n > 0 && row0 >= 0 && row0 + n <= L, "reduce_rows: bad arguments");
     const int grid = (n * d + 255) / 256;
     if (dtype == DT_BF16)
-        hipLaunchKernelGGL(reduce_rows_kernel<BF16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)src_lp, B, L, d, row0, n, out, zero_src, accumulate);
+        hipLaunchKernelGGL(reduce_rows_kernel<BF16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)src_lp, B, L, d, row0, n, out, zero_src, accumulate, scale);
     else if (dtype == DT_F16)
-        hipLaunchKernelGGL(reduce_rows_kernel<F16>, dim3(grid), dim3(256), 0, s, src, (_Float16*)src_lp, B, L, d, row0, n, out, zero_src, accumulate);
+        hipLaunchKernelGGL(reduce_rows_kernel<F16>, dim3(grid), dim3(256), 0, s, src, (_Float16*)src_lp, B, L, d, row0, n, out, zero_src, accumulate, scale);
     else { set_error("reduce_rows: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;

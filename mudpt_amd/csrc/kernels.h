@@ -84,8 +84,9 @@ int launch_patchify(int dtype, const float* images, void* patches, int B, int im
 int launch_set_rows(float* x, int B, int L, int d, int row0, int n, const float* rows, const float* add, hipStream_t s);
 // out[i, :] = sum_b src[b, row0 + i, :] in fixed order (deterministic); optionally zero the source rows
 // (fp32 and its T copy) afterwards: backward of the splice.  accumulate: out += instead of =.
+// scale multiplies the sum (undoes the static loss scale of the backward pass).
 int launch_reduce_rows(int dtype, float* src, void* src_lp, int B, int L, int d, int row0, int n, float* out,
-                       bool zero_src, bool accumulate, hipStream_t s);
+                       bool zero_src, bool accumulate, float scale, hipStream_t s);
 // fp32 C[M,N] = alpha * op(A) . op(B) (+ bias[N]) (+ beta * C); small shapes only (prompt projections, head).
 int launch_sgemm(bool transA, bool transB, int M, int N, int K, float alpha, const float* A, int lda,
                  const float* B, int ldb, float beta, float* C, int ldc, const float* bias, hipStream_t s);
@@ -111,7 +112,7 @@ struct HeadArgs {
     float* txt_n = nullptr;       // [C, e]
     float* img_inv = nullptr;     // [B] 1/||img||
     float* txt_inv = nullptr;     // [C]
-    float grad_scale = 1.f;       // multiplies dloss (1/world for data-parallel mean over the global batch)
+    float grad_scale = 1.f;       // dlogits = (softmax - onehot) * grad_scale / B  (the caller folds loss scaling in here)
     int B = 0, C = 0, e = 0;
 };
 int launch_head_fwd(const HeadArgs& a, hipStream_t s);

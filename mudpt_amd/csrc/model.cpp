@@ -118,6 +118,7 @@ struct mudpt_model {
     size_t off[10];
     size_t numel[10];
     size_t total = 0;
+    float loss_scale = 128.f;  // static, power of two; see mudpt_forward_backward
     // optional HIP-event timing of the MFMA GEMM launches (bench.py's roofline leg)
     bool prof = false;
     std::vector<hipEvent_t> ev;  // pairs
@@ -559,7 +560,12 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     // -- head: cross-entropy (mean) + cosine logits backward, trainers/mudpt.py:178-182,250
     HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.labels = labels; h.scale = m->scale; h.logits = m->logits; h.loss = m->loss; h.dlogits = m->dlogits;
     h.row_loss = m->row_loss; h.dimg = m->dimg; h.dtxt = m->dtxt; h.img_n = m->img_n; h.txt_n = m->txt_n; h.img_inv = m->img_inv; h.txt_inv = m->txt_inv;
-    h.grad_scale = grad_scale; h.B = B; h.C = C; h.e = e;
+    // Static loss scaling: the backward pass runs on per-sample gradients times loss_scale (dlogits = (softmax -
+    // onehot) * loss_scale, independent of B and of the number of ranks), so the T copies of the token gradients
+    // stay inside fp16's normal range (unscaled they are ~1e-7 at B = 256: flushed).  The four reductions that leave
+    // the towers multiply by `unscale`; everything after them is fp32 and linear.
+    const float unscale = grad_scale / ((float)B * m->loss_scale);
+    h.grad_scale = m->loss_scale * (float)B; h.B = B; h.C = C; h.e = e;
     TRY(launch_head_bwd(h, s));
     HIP_TRY(hipMemcpyAsync(loss, m->loss, 4, hipMemcpyDeviceToDevice, s));
 
@@ -574,13 +580,13 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     for (int i = V.layers - 1; i >= 0; --i) {
         TRY(block_bwd(m, V, i, B, s));
         if (i >= 1 && i - 1 < D1)  // backward of the splice: prompt rows feed d(vis_deep[i-1]); the overwritten rows get no gradient
-            TRY(launch_reduce_rows(m->dtype, V.dx, V.dx_lp, B, Lv, dv, Lv - n, n, m->d_vis_deep + (size_t)(i - 1) * n * dv, true, false, s));
+            TRY(launch_reduce_rows(m->dtype, V.dx, V.dx_lp, B, Lv, dv, Lv - n, n, m->d_vis_deep + (size_t)(i - 1) * n * dv, true, false, unscale, s));
     }
     // ln_pre backward on the prompt rows only (patch / CLS rows have no trainable ancestor), in place
     LnBwdArgs bp; bp.dy = V.dx; bp.lddy = dv; bp.dy_f32 = true; bp.x = m->xpre; bp.ldx = dv; bp.row_index = m->vprompt_rows; bp.mean = m->pre_mean; bp.rstd = m->pre_rstd;
     bp.gamma = m->ln_pre_g; bp.dx = V.dx; bp.lddx = dv; bp.rows = B * n; bp.d = dv; bp.by_token = true;
     TRY(launch_ln_bwd(m->dtype, bp, s));
-    TRY(launch_reduce_rows(m->dtype, V.dx, nullptr, B, Lv, dv, Lv - n, n, m->d_vprompt0, false, false, s));
+    TRY(launch_reduce_rows(m->dtype, V.dx, nullptr, B, Lv, dv, Lv - n, n, m->d_vprompt0, false, false, unscale, s));
 
     // -- text tower backward
     Tower& X = m->txt;
@@ -593,10 +599,10 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     for (int i = X.layers - 1; i >= 0; --i) {
         TRY(block_bwd(m, X, i, C, s));
         if (i >= 1 && i - 1 < D1)
-            TRY(launch_reduce_rows(m->dtype, X.dx, X.dx_lp, C, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, s));
+            TRY(launch_reduce_rows(m->dtype, X.dx, X.dx_lp, C, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, unscale, s));
     }
     // d ctx (text side): rows 1..n of the first block's input, summed over the class prompts
-    TRY(launch_reduce_rows(m->dtype, X.dx, nullptr, C, Lt, dt, 1, n, G + m->off[P_CTX], false, true, s));
+    TRY(launch_reduce_rows(m->dtype, X.dx, nullptr, C, Lt, dt, 1, n, G + m->off[P_CTX], false, true, unscale, s));
 
     // -- prompt learner backward (fp32, tiny)
     // visual_ctx and shared = embed_projection(ctx) both receive d_vprompt0 (clip/model.py:534)
@@ -633,6 +639,12 @@ extern "C" int mudpt_sgd_step(mudpt_model* m, float lr, float momentum, float wd
 extern "C" int mudpt_sgd_reset(mudpt_model* m) {
     ARG_CHECK(m, "sgd_reset: null model");
     m->sgd_first = true;
+    return MUDPT_OK;
+}
+
+extern "C" int mudpt_set_loss_scale(mudpt_model* m, float loss_scale) {
+    ARG_CHECK(m && loss_scale > 0.f && std::isfinite(loss_scale), "set_loss_scale: scale must be positive and finite");
+    m->loss_scale = loss_scale;
     return MUDPT_OK;
 }
 
