@@ -43,6 +43,8 @@ def cpu_baseline(iters: int = 8):
     cores at BASELINE config 1's shape: ViT-B/16, n_ctx 4, depth 12, batch 4, 11 classes, fp32."""
     from oracle import mudpt_oracle as O
     from mudpt_amd.synth import bench_tokenized_prompts, CTX_INIT_TOKENS
+    # a one-GPU box owns a 16-core share of the host; more torch threads than that only oversubscribe it
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     cfg = O.VIT_B16
     frozen = O.make_frozen_state(cfg, 0)
     tok = bench_tokenized_prompts().long()

@@ -62,26 +62,39 @@ template <typename T>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(float* __restrict__ src, typename T::elem* __restrict__ src_lp, int B, int L, int d,
                                                           int row0, int n, float* __restrict__ out, bool zero_src, bool accumulate,
                                                           float scale) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * d) return;
-    const int i = idx / d, c = idx % d;
+    // block = 32 columns x 8 batch segments; segment partials are combined in segment order: the summation tree
+    // depends only on (B, launch shape), never on timing -> bitwise reproducible.
+    __shared__ float part[8][33];
+    const int cx = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + cx;
+    const bool live = idx < n * d;
+    const int i = live ? idx / d : 0, c = live ? idx % d : 0;
+    const int per = (B + 7) / 8, b0 = seg * per, b1 = b0 + per < B ? b0 + per : B;
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const size_t o = ((size_t)b * L + row0 + i) * d + c;
-        acc += src[o];
-        if (zero_src) {
-            src[o] = 0.f;
-            if (src_lp) src_lp[o] = (typename T::elem)0.f;
+    if (live)
+        for (int b = b0; b < b1; ++b) {
+            const size_t o = ((size_t)b * L + row0 + i) * d + c;
+            acc += src[o];
+            if (zero_src) {
+                src[o] = 0.f;
+                if (src_lp) src_lp[o] = (typename T::elem)0.f;
+            }
         }
+    part[seg][cx] = acc;
+    __syncthreads();
+    if (seg == 0 && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) t += part[s2][cx];
+        t *= scale;
+        out[idx] = accumulate ? out[idx] + t : t;
     }
-    acc *= scale;
-    out[idx] = accumulate ? out[idx] + acc : acc;
 }
 
 int launch_reduce_rows(int dtype, float* src, void* src_lp, int B, int L, int d, int row0, int n, float* out, bool zero_src,
                        bool accumulate, float scale, hipStream_t s) {
     ARG_CHECK(src && out && B > 0 && n > 0 && row0 >= 0 && row0 + n <= L, "reduce_rows: bad arguments");
-    const int grid = (n * d + 255) / 256;
+    const int grid = (n * d + 31) / 32;
     if (dtype == DT_BF16)
         hipLaunchKernelGGL(reduce_rows_kernel<BF16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)src_lp, B, L, d, row0, n, out, zero_src, accumulate, scale);
     else if (dtype == DT_F16)

@@ -1,0 +1,63 @@
+"""Data-parallel plumbing: one process per GPU, ONE all-reduce per step over the flat gradient bucket.
+
+Replaces the reference's single-process ``nn.DataParallel`` (trainers/mudpt.py:230-233), which re-broadcasts all
+125.6 M parameters every forward and reduces every gradient onto GPU 0.  Here the frozen backbone is resident on
+every rank, images are independent units (no data-path collective) and the only exchange is the sum of the
+4.97 MB fp32 bucket holding the 10 trainable tensors (RCCL over xGMI when the backend is "nccl").
+
+Averaging convention: the reference's loss is ``F.cross_entropy`` (mean) over the concatenated batch
+(trainers/mudpt.py:249-250).  Each rank computes the gradient of (1/world) * mean over its local batch
+(``grad_scale = 1 / world``); the SUM over ranks is then the gradient of the global-batch mean (equal local batches).
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+
+
+def env_rank() -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torch.distributed.run environment (defaults: single process)."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend: str | None = None):
+    """Initialise the default process group when launched with WORLD_SIZE > 1; returns (rank, world, local_rank)."""
+    import torch.distributed as dist
+    rank, world, local = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+    return rank, world, local
+
+
+def world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def grad_scale() -> float:
+    return 1.0 / world_size()
+
+
+def allreduce_grads(flat_grads: torch.Tensor) -> torch.Tensor:
+    """Sum the flat gradient bucket over ranks in place (no-op for a single process)."""
+    if world_size() > 1:
+        import torch.distributed as dist
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+    return flat_grads
+
+
+def broadcast_params(flat_params: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """Make every replica start from rank ``src``'s trainable tensors (replicas otherwise rely on equal seeds)."""
+    if world_size() > 1:
+        import torch.distributed as dist
+        dist.broadcast(flat_params, src)
+    return flat_params
+
+
+def shard(n_items: int, rank: int, world: int) -> range:
+    """Contiguous, equal shards of a global batch; the remainder (if any) is dropped like DataLoader(drop_last=True)."""
+    per = n_items // world
+    return range(rank * per, (rank + 1) * per)

@@ -1,0 +1,157 @@
+"""Drop-in ``MuDPT`` trainer plugin: the reference's ``trainers/mudpt.py:187-302`` surface over libmudpt_hip.so.
+
+Same class name, registry name, hooks and error behaviour as the reference plugin:
+``check_cfg`` (:189), ``build_model`` (:192), ``forward_backward`` (:235), ``parse_batch_train`` (:263),
+inherited ``model_inference`` (``self.model(input)``) and ``load_model`` (:270).  With Dassl installed it subclasses
+``dassl.engine.TrainerX`` and registers in Dassl's ``TRAINER_REGISTRY`` so ``train.py --trainer MuDPT`` and
+``scripts/mudpt/*.sh`` run unchanged; without Dassl it falls back to ``dassl_lite``.
+"""
+from __future__ import annotations
+
+import os.path as osp
+
+import torch
+
+try:  # the real framework, when present
+    from dassl.engine import TRAINER_REGISTRY, TrainerX
+    from dassl.optim import build_optimizer, build_lr_scheduler
+    from dassl.utils import load_checkpoint
+    HAVE_DASSL = True
+except ImportError:  # Dassl is not installed in the build image nor on the GPU box
+    from .dassl_lite import TRAINER_REGISTRY, TrainerX, build_optimizer, build_lr_scheduler, load_checkpoint
+    HAVE_DASSL = False
+
+from . import parallel, synth
+from .model import CustomCLIP, ModelShape
+
+PREC_TO_DTYPE = {"fp16": "fp16", "fp32": "fp16", "amp": "bf16"}
+
+
+def load_clip_state_dict(cfg):
+    """trainers/mudpt.py:20-38 load_clip_to_cpu: a JIT archive or a plain state dict at MODEL.BACKBONE.PATH.
+    The reference's name-based branch is a network download (and dead code); offline it is
+    replaced by an explicit opt-in to seeded random weights (MODEL.BACKBONE.SYNTHETIC_SEED) for benchmarking."""
+    path = cfg.MODEL.BACKBONE.PATH
+    if path:
+        print(f"Loading CLIP backbone: {cfg.MODEL.BACKBONE.NAME} from {path}")
+        try:
+            return torch.jit.load(path, map_location="cpu").eval().state_dict()
+        except RuntimeError:
+            return torch.load(path, map_location="cpu", weights_only=True)
+    seed = cfg.MODEL.BACKBONE.get("SYNTHETIC_SEED", None) if hasattr(cfg.MODEL.BACKBONE, "get") else None
+    if seed is None:
+        raise RuntimeError("MODEL.BACKBONE.PATH is empty and no network is available to download "
+                           f"{cfg.MODEL.BACKBONE.NAME}; set MODEL.BACKBONE.PATH to a local CLIP checkpoint")
+    print(f"Building random-initialised CLIP {cfg.MODEL.BACKBONE.NAME} (seed {seed}) -- synthetic benchmark weights")
+    return None
+
+
+def tokenize_prompts(prompts, ctx_len=77):
+    """clip.tokenize (clip/clip.py:199-239) when the reference's ``clip`` package is importable (drop-in use inside
+    the reference checkout); otherwise the recorded ids of the benchmark prompts."""
+    try:
+        import clip  # the reference's package, present when this plugin is dropped into its checkout
+        return torch.cat([clip.tokenize(p) for p in prompts]).int()
+    except ImportError:
+        table = {f"a photo of a {n}.": i for i, n in enumerate(synth.BENCH_CLASSNAMES)}
+        tok = synth.bench_tokenized_prompts(ctx_len)
+        try:
+            return torch.stack([tok[table[p]] for p in prompts])
+        except KeyError as e:
+            raise RuntimeError(f"no BPE tokenizer available for prompt {e}; run inside the reference checkout (clip/) "
+                               "or use the benchmark class names") from None
+
+
+@TRAINER_REGISTRY.register()
+class MuDPT(TrainerX):
+    def check_cfg(self, cfg):
+        assert cfg.TRAINER.MUDPT.PREC in ["fp16", "fp32", "amp"]  # trainers/mudpt.py:190
+
+    def build_model(self):
+        cfg = self.cfg
+        classnames = self.dm.dataset.classnames
+        mc = cfg.TRAINER.MUDPT
+        assert mc.DEEP_PROMPT_DEPTH > 0, "PROMPT_DEPTH should be > 0"  # trainers/mudpt.py:52
+
+        print(f"Loading CLIP (backbone: {cfg.MODEL.BACKBONE.NAME})")
+        state = load_clip_state_dict(cfg)
+        if state is None:
+            shape = ModelShape(n_ctx=mc.N_CTX, depth=mc.DEEP_PROMPT_DEPTH)
+            state = synth.random_clip_state(shape, cfg.MODEL.BACKBONE.SYNTHETIC_SEED)
+        else:
+            shape = ModelShape.from_state_dict(state, mc.N_CTX, mc.DEEP_PROMPT_DEPTH)
+        cfg_imsize = cfg.INPUT.SIZE[0]
+        assert cfg_imsize == shape.image_size, f"cfg_imsize ({cfg_imsize}) must equal to clip_imsize ({shape.image_size})"  # :55
+
+        # trainers/mudpt.py:57-70,83-85: ctx init words, prompt prefix, "<prefix> <classname>." prompts
+        ctx_init = mc.CTX_INIT
+        if ctx_init:
+            ctx_init = ctx_init.replace("_", " ")
+            prompt_prefix = " ".join(ctx_init.split()[:mc.N_CTX])
+            ctx_ids = [int(v) for v in tokenize_prompts([ctx_init], shape.ctx_len)[0, 1:1 + mc.N_CTX]] \
+                if ctx_init != "a photo of a" else synth.CTX_INIT_TOKENS[:mc.N_CTX]
+        else:
+            print("Initializing A Generic Context")
+            prompt_prefix, ctx_ids = " ".join(["X"] * mc.N_CTX), None
+        print(f'Initial context: "{prompt_prefix}"')
+        print(f"Number of context words (tokens): {mc.N_CTX}")
+        print(f"Depth of deep prompt: {mc.DEEP_PROMPT_DEPTH}")
+        prompts = [prompt_prefix + " " + name.replace("_", " ") + "." for name in classnames]
+        tokenized = tokenize_prompts(prompts, shape.ctx_len)
+
+        print("Building custom CLIP")
+        rank, world, local = parallel.env_rank()
+        max_batch = max(cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.DATALOADER.TEST.BATCH_SIZE)
+        self.model = CustomCLIP(shape, state, tokenized, ctx_token_ids=ctx_ids, max_batch=max_batch,
+                                dtype=PREC_TO_DTYPE[mc.PREC], device=f"cuda:{local}", seed=cfg.SEED)
+        # the freeze rule of trainers/mudpt.py:205-218 is structural here: the module only owns the 10 trainables
+        print(f"Parameters to be updated: {set(self.model.param_names)}")
+
+        self.optim = build_optimizer(self.model, cfg.OPTIM)
+        self.sched = build_lr_scheduler(self.optim, cfg.OPTIM)
+        self.register_model("MultimodalDeepPromptTuning", self.model, self.optim, self.sched)
+        self.scaler = None  # loss scaling lives inside the library (mudpt_set_loss_scale)
+        # the reference wraps in nn.DataParallel when device_count > 1 (:230-233); here: one process per GPU
+        if parallel.world_size() > 1:
+            parallel.broadcast_params(self.model.flat_params)
+
+    def forward_backward(self, batch):
+        image, label = self.parse_batch_train(batch)
+        # forward + F.cross_entropy + backward in one library call; .grad of the 10 tensors is written in place
+        loss = self.model.forward_backward(image, label, grad_scale=parallel.grad_scale())
+        parallel.allreduce_grads(self.model.flat_grads)
+        self.detect_anomaly(loss)  # Dassl's model_backward_and_update does this before backward
+        self.optim.step()
+        loss_summary = {"loss": loss.item()}
+        if (self.batch_idx + 1) == self.num_batches:
+            self.update_lr()
+        return loss_summary
+
+    def parse_batch_train(self, batch):
+        input = batch["img"]
+        label = batch["label"]
+        input = input.to(self.device)
+        label = label.to(self.device)
+        return input, label
+
+    def load_model(self, directory, epoch=None):
+        if not directory:
+            print("Note that load_model() is skipped as no pretrained model is given")
+            return
+        names = self.get_model_names()
+        model_file = "model-best.pth.tar"  # by default, the best model is loaded
+        if epoch is not None:
+            model_file = "model.pth.tar-" + str(epoch)
+        for name in names:
+            model_path = osp.join(directory, name, model_file)
+            if not osp.exists(model_path):
+                raise FileNotFoundError('Model not found at "{}"'.format(model_path))
+            checkpoint = load_checkpoint(model_path)
+            state_dict = checkpoint["state_dict"]
+            epoch = checkpoint["epoch"]
+            # ignore fixed token vectors (trainers/mudpt.py:293-298); the frozen backbone entries of a reference
+            # checkpoint are ignored by strict=False
+            for k in ("mudpt_prompt_learner.token_prefix", "mudpt_prompt_learner.token_suffix"):
+                state_dict.pop(k, None)
+            print("Loading weights to {} " 'from "{}" (epoch = {})'.format(name, model_path, epoch))
+            self._models[name].load_state_dict(state_dict, strict=False)

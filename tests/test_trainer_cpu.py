@@ -1,0 +1,60 @@
+"""Host logic of the drop-in trainer plugin that needs no GPU: registration, cfg checks, error behaviour, schedules."""
+import math
+
+import pytest
+import torch
+
+from mudpt_amd import dassl_lite, trainer
+
+
+def test_plugin_is_registered_under_the_reference_name():
+    assert "MuDPT" in trainer.TRAINER_REGISTRY.registered_names()  # train.py --trainer MuDPT
+    for hook in ("check_cfg", "build_model", "forward_backward", "parse_batch_train", "load_model", "model_inference"):
+        assert callable(getattr(trainer.MuDPT, hook))
+
+
+def test_check_cfg_matches_reference_assert():
+    cfg = dassl_lite.default_cfg()
+    t = object.__new__(trainer.MuDPT)
+    t.check_cfg(cfg)
+    cfg.TRAINER.MUDPT.PREC = "int8"
+    with pytest.raises(AssertionError):  # trainers/mudpt.py:190
+        t.check_cfg(cfg)
+
+
+def test_load_model_error_behaviour(tmp_path):
+    t = object.__new__(trainer.MuDPT)
+    t._models = {"MultimodalDeepPromptTuning": torch.nn.Linear(2, 2)}
+    assert t.load_model("") is None  # "skipped as no pretrained model is given"
+    with pytest.raises(FileNotFoundError):  # trainers/mudpt.py:286-287
+        t.load_model(str(tmp_path), epoch=3)
+
+
+def test_missing_backbone_path_is_an_explicit_error():
+    cfg = dassl_lite.default_cfg()
+    cfg.MODEL.BACKBONE.SYNTHETIC_SEED = None
+    with pytest.raises(RuntimeError, match="MODEL.BACKBONE.PATH"):
+        trainer.load_clip_state_dict(cfg)
+
+
+def test_benchmark_prompts_tokenize_without_the_vocabulary():
+    tok = trainer.tokenize_prompts(["a photo of a face.", "a photo of a binocular."])
+    assert tok.shape == (2, 77) and tok[0, :8].tolist() == [49406, 320, 1125, 539, 320, 1710, 269, 49407]
+    assert tok.argmax(-1).tolist() == [7, 8]
+    with pytest.raises(RuntimeError):
+        trainer.tokenize_prompts(["a photo of a zebra."])
+
+
+def test_constant_warmup_cosine_schedule():
+    p = torch.nn.Parameter(torch.zeros(1))
+    cfg = dassl_lite.default_cfg().OPTIM
+    opt = dassl_lite.build_optimizer(torch.nn.ParameterList([p]), cfg)
+    sch = dassl_lite.build_lr_scheduler(opt, cfg)
+    lrs = []
+    for _ in range(cfg.MAX_EPOCH):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    assert lrs[0] == pytest.approx(1e-5)  # WARMUP_CONS_LR for WARMUP_EPOCH = 1
+    assert lrs[1] == pytest.approx(0.5 * 0.0025 * (1 + math.cos(math.pi * 1 / 10)))
+    assert lrs[-1] < lrs[1]

@@ -1,0 +1,38 @@
+"""The drop-in trainer surface on the GPU: build_model -> forward_backward -> model_inference -> save / load_model."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_trainer_steps_and_checkpoint_roundtrip(tmp_path):
+    from mudpt_amd import dassl_lite, trainer
+    cfg = dassl_lite.default_cfg()
+    cfg.OUTPUT_DIR = str(tmp_path)
+    cfg.OPTIM.MAX_EPOCH = 2
+    cfg.OPTIM.WARMUP_EPOCH = 0
+    cfg.OPTIM.LR = 0.02
+    cfg.DATASET.NUM_TRAIN, cfg.DATASET.NUM_TEST = 8, 8
+    cfg.DATALOADER.TEST.BATCH_SIZE = 8
+    cfg.TRAINER.MUDPT.N_CTX, cfg.TRAINER.MUDPT.DEEP_PROMPT_DEPTH = 4, 12
+    t = dassl_lite.build_trainer(cfg)
+    assert type(t).__name__ == "MuDPT" and t.get_model_names() == ["MultimodalDeepPromptTuning"]
+    assert sorted(t.model.state_dict()) == sorted(t.model.param_names) and len(t.model.param_names) == 10
+    assert sum(p.numel() for p in t.model.parameters()) == 1243136
+    batch = t.train_loader_x[0]
+    t.batch_idx, t.num_batches = 0, 99
+    losses = [t.forward_backward(batch)["loss"] for _ in range(6)]  # same batch: SGD must make progress on it
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    logits = t.model_inference(batch["img"].cuda())
+    assert logits.shape == (4, 11) and torch.isfinite(logits).all()
+    t.save_model(1, str(tmp_path))
+    before = {k: v.clone() for k, v in t.model.state_dict().items()}
+    with torch.no_grad():
+        for p in t.model.parameters():
+            p.add_(1.0)
+    t.load_model(str(tmp_path), epoch=2)
+    for k, v in t.model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert torch.allclose(t.model_inference(batch["img"].cuda()), logits, atol=1e-5)
+    acc = t.test()
+    assert 0.0 <= acc <= 100.0
