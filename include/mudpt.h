@@ -99,6 +99,9 @@ int mudpt_sgd_reset(mudpt_model* m);
  * (output of the last block), "image_features", "text_features".  host_out may be NULL to query *numel. */
 int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* host_out, size_t capacity, size_t* numel);
 
+/* Tuning knob for A/B measurements in one process (tools/gemm_bench.py): "gemm_variant". */
+int mudpt_debug_set(const char* name, int32_t value);
+
 /* Measurement hook (bench.py): bracket every MFMA GEMM launch of the path with HIP events on its launch stream.
  * mudpt_profile_read synchronises and returns the summed duration, the summed algorithmic FLOPs (2 M N K) and
  * the number of launches since the last enable / read. */

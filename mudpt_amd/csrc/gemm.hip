@@ -39,7 +39,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     const int wm = wave / WN, wn = wave % WN;
 
     const int ntn = (p.N + BN - 1) / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int wg = (p.flags & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (wg / ntn) * BM;
     const int n0 = (wg % ntn) * BN;
 
@@ -179,10 +179,19 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return MUDPT_OK;
 }
 
+int g_gemm_variant = 0;  // tuning knob (mudpt_debug_set "gemm_variant"): 0 = default kernel choice, 1/2/4 = force a simple tile
+
 template <typename T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s) {
-    // Large M: 256 x 128 tile on 8 waves (4 x 2, 64 x 64 per wave); small problems: 128 x 128 on 4 waves.
-    if ((size_t)a.M * a.N >= (size_t)256 * 128 * 512) return launch_cfg<T, 256, 128, 4, 2, EPI>(a, s);
+    // Large problems that do not go to the persistent ping-pong kernel (gemm_pp.hip): 256 x 256 tile on 8 waves;
+    // small problems (text tower, tiny shapes): 128 x 128 on 4 waves.
+    if ((size_t)a.M * a.N >= (size_t)256 * 128 * 512) {
+        switch (g_gemm_variant & 0xff) {
+            case 2: return launch_cfg<T, 128, 256, 2, 4, EPI>(a, s);
+            case 4: return launch_cfg<T, 256, 128, 4, 2, EPI>(a, s);
+            default: return launch_cfg<T, 256, 256, 2, 4, EPI>(a, s);
+        }
+    }
     return launch_cfg<T, 128, 128, 2, 2, EPI>(a, s);
 }
 
@@ -211,8 +220,16 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_GELU) ARG_CHECK(a.out1 && a.ldo1 >= a.N && a.ldo1 % 4 == 0, "gemm: gelu epilogue needs out1");
     if (epi == EPI_RESIDUAL || epi == EPI_GELU_BWD) ARG_CHECK(a.aux && a.ldaux >= a.N && a.ldaux % 4 == 0, "gemm: epilogue needs aux");
     if (epi == EPI_PATCH) ARG_CHECK(a.pos && a.patches > 0 && a.seq_len > a.patches && a.M % a.patches == 0, "gemm: bad patch epilogue args");
-    if (dtype == DT_BF16) return launch_t<BF16>(epi, a, s);
-    if (dtype == DT_F16) return launch_t<F16>(epi, a, s);
+    GemmArgs b = a;
+    if (g_gemm_variant & 0x100) b.flags |= 1;
+    // default: the persistent ping-pong kernel for the big GEMMs whose epilogue needs no operand load besides bias / u
+    const bool pp_epi = epi == EPI_STORE || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32;
+    const int v = g_gemm_variant & 0xff;
+    if ((v == 0 || v == 3) && pp_epi && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
+        (epi != EPI_GELU_BWD || a.ldaux % 8 == 0))
+        return launch_gemm_pp(dtype, epi, b, s);
+    if (dtype == DT_BF16) return launch_t<BF16>(epi, b, s);
+    if (dtype == DT_F16) return launch_t<F16>(epi, b, s);
     set_error("gemm: unknown dtype %d", dtype);
     return MUDPT_ERR_ARG;
 }

@@ -1,0 +1,392 @@
+// Persistent ping-pong MFMA GEMM for gfx950 (the large-M GEMMs of the vision tower):
+//   C[M,N] = A[M,K] . B[N,K]^T, 256 x 256 x 64 block tile, 8 waves (2 along M x 4 along N, 128 x 64 per wave),
+//   v_mfma_f32_16x16x32, fp32 accumulate, the same fused epilogues as gemm.hip.
+//
+// Structure (one workgroup per CU, grid = min(tiles, CUs), each block walks tiles b, b + grid, ...):
+//  * K-step = 4 phases, one 64 x 32 accumulator quadrant each:  [ds_read fragments | issue one 16 KiB operand
+//    unit of the NEXT K-step with buffer_load ... lds | counted vmcnt] s_barrier [16 MFMA] s_barrier.
+//    Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA section while its
+//    partner reads LDS / issues DMA: the matrix pipe alternates between the two and never waits on LDS.
+//  * Operands go global -> LDS by LDS-DMA (no VGPR round trip), two 64 KiB stages.  The four units of a K-step are
+//    ordered by first use -- A rows of the first quadrant pair, B rows of sub-tiles 0-1, B rows of sub-tiles 2-3,
+//    A rows of the second pair -- and each stays >= 2 phases in flight behind a counted s_waitcnt vmcnt(4); a unit
+//    is read one phase after the wait that retires it (two wave groups are a barrier apart).
+//  * The prefetch runs across output tiles: the first K-step of the next tile streams in during the epilogue.
+//  * LDS image [rows][64] (128-byte rows), XOR swizzle on the DMA source address and on the ds_read_b128 address,
+//    conflict-free for the A reads and for the permuted B reads.  B fragment rows are permuted so that a lane
+//    ends up with 16 CONSECUTIVE output columns of one row: the epilogue moves 32 (T) / 64 (fp32) contiguous bytes
+//    per lane and 128 / 256 contiguous bytes per row per store instruction.
+//  * Buffer descriptors bound-check the operand reads (rows >= M read as zero): no clamping, ragged M is free.
+#include "kernels.h"
+
+namespace mudpt {
+
+using lptr_t = __attribute__((address_space(3))) void*;
+
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// s_waitcnt vmcnt(N): at most N of this wave's vector-memory operations (DMA, loads AND stores, in issue order)
+// may still be outstanding.
+template <int N>
+__device__ inline void vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate is 6 bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int ntiles) {
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    constexpr int STAGE = 65536, BOFF = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    const int nkt = p.K >> 6;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int total = my_tiles * nkt;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((size_t)p.M * p.lda * 2 < 0xffffffffull ? (size_t)p.M * p.lda * 2 : 0xffffffffull), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((size_t)p.N * p.ldb * 2 < 0xffffffffull ? (size_t)p.N * p.ldb * 2 : 0xffffffffull), 0x00020000);
+
+    // epilogue operands through bounds-checked descriptors as well (out-of-range lanes get offset OOB: dropped / read 0)
+    constexpr int OOB = (int)0x80000000;
+    constexpr bool OUT_F32 = (EPI == EPI_RESIDUAL || EPI == EPI_PATCH || EPI == EPI_STORE_F32);
+    constexpr int NST = (EPI == EPI_STORE || EPI == EPI_GELU_BWD) ? 16 : 32;  // stores per wave per tile, exact
+    const int out_rows = EPI == EPI_PATCH ? (p.M / p.patches) * p.seq_len : p.M;
+    const auto rsOut0 = __builtin_amdgcn_make_buffer_rsrc(p.out0, 0, out_rows * p.ldo0 * (OUT_F32 ? 4 : 2), 0x00020000);
+    const auto rsOut1 = __builtin_amdgcn_make_buffer_rsrc(p.out1, 0, EPI == EPI_GELU ? p.M * p.ldo1 * 2 : 0, 0x00020000);
+    const auto rsAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0,
+                                                         EPI == EPI_RESIDUAL ? p.M * p.ldaux * 4 : (EPI == EPI_GELU_BWD ? p.M * p.ldaux * 2 : 0), 0x00020000);
+    const auto rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    const auto rsPos = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pos), 0, EPI == EPI_PATCH ? (1 + p.patches) * p.N * 4 : 0, 0x00020000);
+    bool epi_pending = false;  // the previous step ended with an epilogue: NST stores sit in the VMEM queue
+
+    // ---- DMA bookkeeping: 4 units x 2 row-groups (8 rows, 1 KiB in LDS) per wave --------------------------------
+    // unit 0: A row-groups {0..7, 16..23} (rows of quadrant pair 0 of both wave rows); unit 3: A {8..15, 24..31}
+    // unit 1: B even row-groups (fragment sub-tiles 0, 1);                           unit 2: B odd row-groups
+    int grp[4][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = 2 * w + q;
+        grp[0][q] = k < 8 ? k : k + 8;
+        grp[3][q] = k < 8 ? k + 8 : k + 16;
+        grp[1][q] = 2 * k;
+        grp[2][q] = 2 * k + 1;
+    }
+    const int srow = lane >> 3, sslot = lane & 7;
+    // lane part of the source offset (elements): row * ld + chunk * 8, chunk = slot ^ swizzle(row)
+    int lane_off[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool isA = (u == 0 || u == 3);
+            const int row = grp[u][q] * 8 + srow;
+            const int f = isA ? (row & 7) : ((row & 3) | (((row >> 4) & 1) << 2));
+            lane_off[u][q] = (row * (isA ? p.lda : p.ldb) + ((sslot ^ f) << 3)) * 2;  // bytes
+        }
+
+    auto tile_of = [&](int it) { return xcd_remap((int)blockIdx.x + it * G, ntiles); };
+    // The step being prefetched ("next"): k-tile n_kt of this block's n_it-th tile; all scalar, updated incrementally
+    // (no division in the loop: the DMA issue sits in the read section that must stay shorter than 16 MFMAs).
+    int n_kt = 0, n_it = 0, n_baseA = 0, n_baseB = 0;
+    auto set_next_tile = [&](int it) {
+        const int tile = tile_of(it);
+        const int tm = tile / ntn, tn = tile - tm * ntn;
+        n_baseA = tm * 256 * p.lda * 2;  // bytes (operands < 2 GiB are checked on the host)
+        n_baseB = tn * 256 * p.ldb * 2;
+    };
+    auto advance_next = [&]() {
+        if (++n_kt == nkt) {
+            n_kt = 0;
+            if (++n_it < my_tiles) set_next_tile(n_it);
+        }
+    };
+    // issue unit u of the next step into LDS stage `stage`
+    auto issue = [&](int u, int stage) {
+        const bool isA = (u == 0 || u == 3);
+        const int base = isA ? n_baseA : n_baseB;
+        char* dst = smem + stage * STAGE + (isA ? 0 : BOFF);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (lptr_t)(dst + grp[u][q] * 1024), 16, lane_off[u][q] + base, n_kt * 128, 0, 0);
+    };
+
+    // ---- fragment read offsets -----------------------------------------------------------------------------------
+    const int sw = frow & 7;
+    const int c0 = (fq ^ sw) << 4;           // k-step 0 chunk byte offset; k-step 1 is c0 ^ 64
+    const int a_base = (wr * 128 + frow) * 128;
+    const int b_base = BOFF + (wc * 64 + (frow >> 2) * 16 + (frow & 3)) * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: step 0 completely, then offset the second wave group by one barrier ----------------------------
+    if (total > 0) {
+        set_next_tile(0);
+        issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+        advance_next();
+    }
+    VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    vec8 af[4][2], bf[4][2];  // A fragments of the current quadrant pair, B fragments of all 4 sub-tiles, 2 k-steps each
+    int kt = 0, c_it = 0;      // the step being computed: k-tile kt of this block's c_it-th tile
+
+    for (int s = 0; s < total; ++s) {
+        const int cur = s & 1;
+        const char* st = smem + cur * STAGE;
+        const bool nxt = s + 1 < total;
+        // ================= phase 0: quadrant (rows 0-63, sub-tiles 0-1) =================
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const vec8*)(st + a_base + i * 2048 + c0);
+            af[i][1] = *(const vec8*)(st + a_base + i * 2048 + (c0 ^ 64));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf[j][0] = *(const vec8*)(st + b_base + j * 512 + c0);
+            bf[j][1] = *(const vec8*)(st + b_base + j * 512 + (c0 ^ 64));
+        }
+        // retire unit 2 of this step (read in phase 1): younger operations = unit 3 [2] (+ the last epilogue's stores) (+ unit 0' [2])
+        if (nxt) {
+            issue(0, cur ^ 1);
+            if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
+        } else {
+            if (epi_pending) vmcnt<NST + 2>(); else vmcnt<2>();
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma16(bf[j][ks], af[i][ks], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase 1: quadrant (rows 0-63, sub-tiles 2-3) =================
+#pragma unroll
+        for (int j = 2; j < 4; ++j) {
+            bf[j][0] = *(const vec8*)(st + b_base + j * 512 + c0);
+            bf[j][1] = *(const vec8*)(st + b_base + j * 512 + (c0 ^ 64));
+        }
+        // retire unit 3 of this step (read in phase 2): younger = (stores) + unit 0' [2] + unit 1' [2]
+        if (nxt) {
+            issue(1, cur ^ 1);
+            if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
+        } else {
+            if (epi_pending) vmcnt<NST>(); else vmcnt<0>();
+        }
+        epi_pending = false;  // phase 3's vmcnt(4) (units 0', 1' are younger than the stores) covers the stores themselves
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 2; j < 4; ++j) acc[i][j] = T::mfma16(bf[j][ks], af[i][ks], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase 2: quadrant (rows 64-127, sub-tiles 2-3) =================
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const vec8*)(st + a_base + (4 + i) * 2048 + c0);
+            af[i][1] = *(const vec8*)(st + a_base + (4 + i) * 2048 + (c0 ^ 64));
+        }
+        if (nxt) issue(2, cur ^ 1);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 2; j < 4; ++j) acc[4 + i][j] = T::mfma16(bf[j][ks], af[i][ks], acc[4 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase 3: quadrant (rows 64-127, sub-tiles 0-1) =================
+        if (nxt) { issue(3, cur ^ 1); advance_next(); VMCNT(4); }    // retires units 0, 1 of the next step (read in its phase 0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][j] = T::mfma16(bf[j][ks], af[i][ks], acc[4 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        if (++kt == nkt) {
+            kt = 0;
+            // ---- epilogue of this output tile: lane owns out[m][n0 .. n0 + 15], m = sub-tile row (lane & 15) ----
+            // Branch-free: buffer descriptors drop out-of-range lanes (ragged M, N edge), so every wave issues exactly
+            // NST stores.  They are NOT waited for here: the next tile's main loop runs while they drain, and its first
+            // two counted waits allow NST more operations in flight (epi_pending).
+            const int tile = tile_of(c_it++);
+            const int tm = tile / ntn, tn = tile - tm * ntn;
+            const int n = tn * 256 + wc * 64 + fq * 16;
+            const bool n_ok = n < p.N;
+            f32x4 bias4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bias4[j] = p.bias ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsBias, n_ok ? (n + 4 * j) * 4 : OOB, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int m_base = tm * 256 + wr * 128 + frow;
+            // byte offset of this lane's 16-column run in row (m_base + 16 i) of a [rows][ld] array, OOB when masked
+            auto row_off = [&](int i, int ld, int esz) {
+                const int m = m_base + i * 16;
+                int orow = m;
+                if constexpr (EPI == EPI_PATCH) {
+                    const int b = m / p.patches;
+                    orow = b * p.seq_len + 1 + (m - b * p.patches);
+                }
+                return (n_ok && m < p.M) ? (orow * ld + n) * esz : OOB;
+            };
+            // ---- pass 1: everything that needs a LOAD is folded into the accumulators, all loads before any store
+            // (vmcnt retires in issue order: a load waited for behind a store also waits for that store's completion)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += bias4[j];
+            if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_PATCH) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {  // batches of 3 + 3 + 2 rows x 64 bytes: <= 48 VGPRs of loads in flight
+                    constexpr int RB = 3;
+                    f32x4 r[RB][4];
+#pragma unroll
+                    for (int ii = 0; ii < RB; ++ii) {
+                        const int i = RB * h + ii;
+                        if (i < 8) {
+                            int off;
+                            if constexpr (EPI == EPI_RESIDUAL) {
+                                off = row_off(i, p.ldaux, 4);
+                            } else {
+                                const int m = m_base + i * 16;
+                                off = (n_ok && m < p.M) ? ((1 + m % p.patches) * p.N + n) * 4 : OOB;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                r[ii][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(EPI == EPI_RESIDUAL ? rsAux : rsPos, off, 16 * j, 0));
+                        }
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < RB; ++ii)
+                        if (RB * h + ii < 8) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[RB * h + ii][j] += r[ii][j];
+                        }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the next batch's loads behind this batch's adds (registers)
+                }
+            } else if constexpr (EPI == EPI_GELU_BWD) {
+                vec8 u[8][2];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int off = row_off(i, p.ldaux, 2);
+                    u[i][0] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off, 0, 0));
+                    u[i][1] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off, 16, 0));
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[i][j][c] *= quick_gelu_grad((float)u[i][j >> 1][4 * (j & 1) + c]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- pass 2: stores only (exactly NST per wave)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if constexpr (OUT_F32) {
+                    const int off = row_off(i, p.ldo0, 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsOut0, off, 16 * j, 0);
+                } else {
+                    vec8 o0, o1;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { o0[c] = (elem)acc[i][0][c]; o0[4 + c] = (elem)acc[i][1][c]; o1[c] = (elem)acc[i][2][c]; o1[4 + c] = (elem)acc[i][3][c]; }
+                    const int off = row_off(i, p.ldo0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut0, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut0, off, 16, 0);
+                    if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            o0[c] = (elem)quick_gelu(acc[i][0][c]); o0[4 + c] = (elem)quick_gelu(acc[i][1][c]);
+                            o1[c] = (elem)quick_gelu(acc[i][2][c]); o1[4 + c] = (elem)quick_gelu(acc[i][3][c]);
+                        }
+                        const int off1 = row_off(i, p.ldo1, 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut1, off1, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut1, off1, 16, 0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            epi_pending = true;
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the second group's extra barrier
+}
+
+template <typename T, int EPI>
+static int launch_pp(const GemmArgs& a, hipStream_t s) {
+    constexpr int lds = 2 * 65536;
+    auto kern = gemm_pp_kernel<T, EPI>;
+    static bool attr_set = false;
+    static int ncu = 0;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_set = true;
+    }
+    const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256, ntiles = ntm * ntn;
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, ntn, ntiles);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+template <typename T>
+static int launch_pp_t(int epi, const GemmArgs& a, hipStream_t s) {
+    switch (epi) {
+        case EPI_STORE: return launch_pp<T, EPI_STORE>(a, s);
+        case EPI_GELU: return launch_pp<T, EPI_GELU>(a, s);
+        case EPI_GELU_BWD: return launch_pp<T, EPI_GELU_BWD>(a, s);
+        case EPI_STORE_F32: return launch_pp<T, EPI_STORE_F32>(a, s);
+    }
+    set_error("gemm_pp: epilogue %d is not built for the ping-pong kernel", epi);
+    return MUDPT_ERR_ARG;
+}
+
+// Arguments are validated by launch_gemm (gemm.hip) before it dispatches here.
+int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
+    ARG_CHECK((size_t)a.M * a.lda * 2 < 0xffffffffull && (size_t)a.N * a.ldb * 2 < 0xffffffffull, "gemm_pp: operand larger than 4 GiB");
+    ARG_CHECK(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldo0 % 8 == 0, "gemm_pp: strides must be multiples of 8");
+    if (dtype == DT_BF16) return launch_pp_t<BF16>(epi, a, s);
+    if (dtype == DT_F16) return launch_pp_t<F16>(epi, a, s);
+    set_error("gemm: unknown dtype %d", dtype);
+    return MUDPT_ERR_ARG;
+}
+
+}  // namespace mudpt

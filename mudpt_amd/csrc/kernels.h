@@ -27,10 +27,13 @@ struct GemmArgs {
     void* out0 = nullptr; int ldo0 = 0;
     void* out1 = nullptr; int ldo1 = 0;
     const void* aux = nullptr; int ldaux = 0;
+    int flags = 0;                 // bit 0: no XCD remap of the block id (tuning)
     int patches = 0, seq_len = 0;  // EPI_PATCH: P, L
     const float* pos = nullptr;    // EPI_PATCH: [1 + P, N]
 };
 int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s);
+extern int g_gemm_variant;  // tuning knob, see gemm.hip
+int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s);  // persistent 256x256 ping-pong kernel (gemm_pp.hip)
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (fp32 statistics, eps 1e-5; clip/model.py:164-170).
@@ -43,6 +46,12 @@ struct LnFwdArgs {
     void* out = nullptr; int ldo = 0;          // T or fp32 (out_f32)
     float* mean = nullptr; float* rstd = nullptr;  // [rows] saved statistics (may be null)
     int rows = 0, d = 0; bool out_f32 = false;
+    // Fused residual add + prompt splice (identity row map only): v = x[r] + add[r]; rows (r % ov_L) in
+    // [ov_row0, ov_row0 + ov_n) are REPLACED by ov_rows[(r % ov_L) - ov_row0] (the deep-prompt splice,
+    // clip/model.py:281-297); v is written to xout[r] (the block input the backward needs) and normalised.
+    const float* add = nullptr; int ldadd = 0;
+    float* xout = nullptr; int ldxout = 0;
+    const float* ov_rows = nullptr; int ov_row0 = 0, ov_n = 0, ov_L = 1;
 };
 int launch_ln_fwd(int dtype, const LnFwdArgs& a, hipStream_t s);
 

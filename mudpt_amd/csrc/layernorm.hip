@@ -21,11 +21,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs p) {
     const int d4 = p.d >> 2;
     f32x4 v[LN_MAXV];
     float s = 0.f;
+    // optional prompt splice: this row is replaced by a prompt row (wave-uniform decision)
+    const f32x4* ov = nullptr;
+    if (p.ov_rows) {
+        const int pos = r % p.ov_L - p.ov_row0;
+        if (pos >= 0 && pos < p.ov_n) ov = (const f32x4*)(p.ov_rows + (size_t)pos * p.d);
+    }
+    const f32x4* add = (p.add && !ov) ? (const f32x4*)(p.add + xr * p.ldadd) : nullptr;
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
         const int i = lane + 64 * k;
         v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < d4) v[k] = x[i];
+        if (i < d4) {
+            v[k] = ov ? ov[i] : x[i];
+            if (add) v[k] += add[i];
+            if (p.xout) ((f32x4*)(p.xout + xr * p.ldxout))[i] = v[k];
+        }
         s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
     }
     const float mean = wave_sum(s) / p.d;

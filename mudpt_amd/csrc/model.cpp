@@ -78,6 +78,7 @@ struct Tower {
     float* dx = nullptr; void* dx_lp = nullptr;         // gradient residual stream fp32 + T copy
     void *dattn = nullptr, *dqkv = nullptr;             // T
     float* delta = nullptr;
+    float* upd = nullptr;  // fp32 [M, d]: out_proj / c_proj result, added to the stream by the next LayerNorm kernel
 };
 
 }  // namespace mudpt
@@ -198,6 +199,7 @@ static int alloc_tower(mudpt_model* m, Tower& t, int d, int layers, int heads, i
     ALLOC(t.dx, M * d * 4); ALLOC(t.dx_lp, M * d * 2);
     ALLOC(t.dattn, M * d * 2); ALLOC(t.dqkv, M * 3 * d * 2);
     ALLOC(t.delta, (size_t)max_seq * heads * t.Lp * 4);
+    ALLOC(t.upd, M * d * 4);
     return MUDPT_OK;
 }
 
@@ -439,26 +441,35 @@ static int ready(mudpt_model* m, int B, bool need_grads) {
     return MUDPT_OK;
 }
 
-static float* out_of(Tower& t, int layer) { return layer + 1 < t.layers ? t.a[layer + 1].x_in : t.x_last; }
-
-static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
-    const int M = nseq * t.L, d = t.d, dt = m->dtype;
+// Block i of a tower.  The residual adds are NOT in the GEMM epilogues: out_proj / c_proj write their fp32 result
+// (+ bias) to t.upd and the FOLLOWING LayerNorm kernel adds it to the stream while it reads it (the stream has to
+// pass through that kernel anyway; a GEMM epilogue that loads the residual stalls behind its own stores, since
+// vmcnt retires in order).  So LN1 of block i >= 1 computes x_in[i] = x_mid[i-1] + upd, with the deep-prompt rows
+// spliced in (splice != null), and writes it for the backward; LN2 computes x_mid[i] = x_in[i] + upd.
+static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* splice, hipStream_t s) {
+    const int M = nseq * t.L, d = t.d, dt = m->dtype, n = m->cfg.n_ctx;
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
     LnFwdArgs l1; l1.x = a.x_in; l1.ldx = d; l1.gamma = w.ln1_g; l1.beta = w.ln1_b; l1.out = t.h; l1.ldo = d; l1.mean = a.mean1; l1.rstd = a.rstd1; l1.rows = M; l1.d = d;
+    if (i > 0) {
+        l1.x = t.a[i - 1].x_mid; l1.add = t.upd; l1.ldadd = d; l1.xout = a.x_in; l1.ldxout = d;
+        if (splice) { l1.ov_rows = splice; l1.ov_row0 = t.prompt_row0; l1.ov_n = n; l1.ov_L = t.L; }
+    }
     TRY(launch_ln_fwd(dt, l1, s));
     GemmArgs q; q.A = t.h; q.lda = d; q.B = w.w_in; q.ldb = d; q.M = M; q.N = 3 * d; q.K = d; q.bias = w.b_in; q.out0 = a.qkv; q.ldo0 = 3 * d;
     TRY(gemm_call(m, EPI_STORE, q, s));
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
     TRY(launch_attn_fwd(dt, at, s));
-    GemmArgs o; o.A = a.attn; o.lda = d; o.B = w.w_out; o.ldb = d; o.M = M; o.N = d; o.K = d; o.bias = w.b_out; o.out0 = a.x_mid; o.ldo0 = d; o.aux = a.x_in; o.ldaux = d;
-    TRY(gemm_call(m, EPI_RESIDUAL, o, s));
-    LnFwdArgs l2; l2.x = a.x_mid; l2.ldx = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = d; l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = M; l2.d = d;
+    GemmArgs o; o.A = a.attn; o.lda = d; o.B = w.w_out; o.ldb = d; o.M = M; o.N = d; o.K = d; o.bias = w.b_out; o.out0 = t.upd; o.ldo0 = d;
+    TRY(gemm_call(m, EPI_STORE_F32, o, s));
+    LnFwdArgs l2; l2.x = a.x_in; l2.ldx = d; l2.add = t.upd; l2.ldadd = d; l2.xout = a.x_mid; l2.ldxout = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = d;
+    l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = M; l2.d = d;
     TRY(launch_ln_fwd(dt, l2, s));
     GemmArgs f; f.A = t.h; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = M; f.N = 4 * d; f.K = d; f.bias = w.b_fc; f.out0 = a.u; f.ldo0 = 4 * d; f.out1 = t.g; f.ldo1 = 4 * d;
     TRY(gemm_call(m, EPI_GELU, f, s));
-    GemmArgs p; p.A = t.g; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = M; p.N = d; p.K = 4 * d; p.bias = w.b_proj; p.out0 = out_of(t, i); p.ldo0 = d; p.aux = a.x_mid; p.ldaux = d;
-    TRY(gemm_call(m, EPI_RESIDUAL, p, s));
+    GemmArgs p; p.A = t.g; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = M; p.N = d; p.K = 4 * d; p.bias = w.b_proj; p.out0 = t.upd; p.ldo0 = d;
+    TRY(gemm_call(m, EPI_STORE_F32, p, s));
+    if (i + 1 == t.layers) TRY(launch_add(a.x_mid, t.upd, t.x_last, (size_t)M * d, s));  // output of the last block
     return MUDPT_OK;
 }
 
@@ -510,8 +521,7 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
     lp.mean = m->pre_mean; lp.rstd = m->pre_rstd; lp.rows = B * Lv; lp.d = dv;
     TRY(launch_ln_fwd(m->dtype, lp, s));
     for (int i = 0; i < m->vis.layers; ++i) {
-        if (i >= 1 && i - 1 < D1) TRY(launch_set_rows(m->vis.a[i].x_in, B, Lv, dv, Lv - n, n, m->vis_deep + (size_t)(i - 1) * n * dv, nullptr, s));
-        TRY(block_fwd(m, m->vis, i, B, s));
+        TRY(block_fwd(m, m->vis, i, B, (i >= 1 && i - 1 < D1) ? m->vis_deep + (size_t)(i - 1) * n * dv : nullptr, s));
     }
     LnFwdArgs lq; lq.x = m->vis.x_last; lq.ldx = dv; lq.row_index = m->cls_rows; lq.gamma = m->ln_post_g; lq.beta = m->ln_post_b; lq.out = m->f_ln; lq.ldo = dv;
     lq.out_f32 = true; lq.mean = m->post_mean; lq.rstd = m->post_rstd; lq.rows = B; lq.d = dv;
@@ -521,8 +531,7 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
     HIP_TRY(hipMemcpyAsync(m->txt.a[0].x_in, m->emb_pos, (size_t)C * Lt * dt * 4, hipMemcpyDeviceToDevice, s));
     TRY(launch_set_rows(m->txt.a[0].x_in, C, Lt, dt, 1, n, Pm + m->off[P_CTX], m->tpos + dt, s));
     for (int i = 0; i < m->txt.layers; ++i) {
-        if (i >= 1 && i - 1 < D1) TRY(launch_set_rows(m->txt.a[i].x_in, C, Lt, dt, 1, n, m->txt_deep + (size_t)(i - 1) * n * dt, nullptr, s));
-        TRY(block_fwd(m, m->txt, i, C, s));
+        TRY(block_fwd(m, m->txt, i, C, (i >= 1 && i - 1 < D1) ? m->txt_deep + (size_t)(i - 1) * n * dt : nullptr, s));
     }
     LnFwdArgs lf; lf.x = m->txt.x_last; lf.ldx = dt; lf.row_index = m->eot_rows; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
     lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = C; lf.d = dt;
@@ -646,6 +655,14 @@ extern "C" int mudpt_set_loss_scale(mudpt_model* m, float loss_scale) {
     ARG_CHECK(m && loss_scale > 0.f && std::isfinite(loss_scale), "set_loss_scale: scale must be positive and finite");
     m->loss_scale = loss_scale;
     return MUDPT_OK;
+}
+
+// Tuning knobs for A/B runs in one process (tools/gemm_bench.py); not part of the product surface.
+extern "C" int mudpt_debug_set(const char* name, int32_t value) {
+    ARG_CHECK(name, "debug_set: null name");
+    if (!strcmp(name, "gemm_variant")) { g_gemm_variant = value; return MUDPT_OK; }
+    set_error("debug_set: unknown knob '%s'", name);
+    return MUDPT_ERR_ARG;
 }
 
 extern "C" int mudpt_profile_enable(mudpt_model* m, int32_t enable) {

@@ -145,6 +145,24 @@ def test_layernorm_fwd_bwd(lib, dtype, rows, d):
     torch.testing.assert_close(dx_lp.cpu().float(), dx_ref + dres, atol=4 * EPS[dtype] * 4, rtol=4 * EPS[dtype])
 
 
+def test_layernorm_fused_add_and_prompt_splice():
+    """LN forward with the residual add and the deep-prompt splice fused in (what block_fwd uses): rows outside the
+    prompt range are x + add, prompt rows are REPLACED by the given rows; the block input is written back."""
+    from mudpt_amd import capi
+    import ctypes
+    lib = capi.load()
+    # not exported as a single-kernel entry point with these extras: exercised through a tiny model forward instead
+    # (tests/test_model_gpu.py::test_block_outputs_match_reference_fp16 compares every block's input and output);
+    # here: the plain kernel must be unaffected by the new arguments being absent.
+    d, rows = 256, 9
+    x = torch.randn(rows, d).cuda()
+    g, b = torch.ones(d).cuda(), torch.zeros(d).cuda()
+    out = torch.empty(rows, d, device="cuda")
+    ok(lib, lib.mudpt_layernorm_fwd(0, P(x), d, None, P(g), P(b), P(out), d, 1, None, None, rows, d, None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu(), torch.nn.functional.layer_norm(x.cpu(), (d,)), atol=2e-5, rtol=1e-5)
+
+
 def test_layernorm_gather_scatter(lib):
     """row_index: LN of selected token rows (ln_post on CLS rows, ln_final on EOT rows) and the scatter of its gradient."""
     rows, d, total = 6, 256, 40
@@ -221,3 +239,69 @@ def test_attention_softmax_extremes(lib):
     torch.cuda.synchronize()
     assert torch.isfinite(out).all() and torch.isfinite(lse[:, :, :L]).all()
     torch.testing.assert_close(out.cpu().float(), ref, atol=4e-3, rtol=4e-3)
+
+
+@pytest.fixture
+def gemm_variant(lib):
+    def set_variant(v):
+        assert lib.mudpt_debug_set(b"gemm_variant", v) == 0
+    yield set_variant
+    lib.mudpt_debug_set(b"gemm_variant", 0)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gemm_variants_exact_integers(lib, gemm_variant, variant, dtype):
+    """Every large-problem GEMM kernel (0 = default: persistent ping-pong kernel; 1, 2, 4 = simple 256x256, 128x256,
+    256x128 tiles): exact small-integer operands, ragged M, asymmetric B, K spanning several tiles -> bit-exact."""
+    dt, tt = DT[dtype]
+    M, N, K = 16500, 1024, 192
+    g = torch.Generator().manual_seed(1)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = (torch.arange(N).view(N, 1) % 7 - 3 + (torch.arange(K).view(1, K) % 3)).float()
+    ref = A @ B.t()
+    out = torch.full((M, N), -1.0, device="cuda", dtype=torch.float32)
+    gemm_variant(variant)
+    gemm(lib, dt, 5, A.cuda().to(tt), B.cuda().to(tt), out0=out)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(33000, 768, 768), (8200, 2304, 768), (22000, 768, 3072)])
+def test_gemm_pingpong_epilogues(lib, gemm_variant, dtype, shape):
+    dt, tt = DT[dtype]
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(tt)
+    B = (torch.randn(N, K, generator=g) * K ** -0.5).to(tt)
+    bias = torch.randn(N, generator=g)
+    acc = A.float() @ B.float().t()  # fp32 CPU reference (fp64 is too slow at this size); tolerances account for it
+    Ad, Bd, bd = A.cuda(), B.cuda(), bias.cuda()
+    tol = dict(atol=4 * EPS[dtype], rtol=4 * EPS[dtype])
+    f32tol = dict(atol=3e-5 * K ** 0.5, rtol=2e-5)
+    gemm_variant(0)  # default dispatch: ping-pong kernel for store / GELU / GELU' / fp32 store, simple 256x256 for residual
+    out = torch.empty(M, N, device="cuda", dtype=tt)
+    gemm(lib, dt, 0, Ad, Bd, bias=bd, out0=out)
+    torch.testing.assert_close(out.cpu().float(), acc + bias, **tol)
+    o32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    gemm(lib, dt, 5, Ad, Bd, out0=o32)
+    torch.testing.assert_close(o32.cpu(), acc, **f32tol)
+    u, gl = torch.empty(M, N, device="cuda", dtype=tt), torch.empty(M, N, device="cuda", dtype=tt)
+    gemm(lib, dt, 1, Ad, Bd, bias=bd, out0=u, out1=gl)
+    uref = acc + bias
+    torch.testing.assert_close(u.cpu().float(), uref, **tol)
+    torch.testing.assert_close(gl.cpu().float(), uref * torch.sigmoid(1.702 * uref), **tol)
+    res = torch.randn(M, N, generator=g)
+    resd = res.cuda()
+    gemm(lib, dt, 2, Ad, Bd, bias=bd, out0=o32, aux=resd)
+    torch.testing.assert_close(o32.cpu(), res + uref, **f32tol)
+    upre = torch.randn(M, N, generator=g).to(tt)
+    upred = upre.cuda()
+    gemm(lib, dt, 3, Ad, Bd, out0=out, aux=upred)
+    s = torch.sigmoid(1.702 * upre.float())
+    torch.testing.assert_close(out.cpu().float(), acc * (s * (1 + 1.702 * upre.float() * (1 - s))), **tol)
+    # repeated launches give identical bits (no race in the DMA / barrier protocol shows up as run-to-run change)
+    ref_bits = out.clone()
+    for _ in range(5):
+        gemm(lib, dt, 3, Ad, Bd, out0=out, aux=upred)
+        assert torch.equal(out, ref_bits)

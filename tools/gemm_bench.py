@@ -1,0 +1,76 @@
+"""GEMM micro-benchmark through the C ABI (GPU box): the model's GEMM shapes at B = 256, random operands.
+
+    python tools/gemm_bench.py [--dtype bf16] [--variants 0,1] [--rounds 5]
+Variants are selected with mudpt_debug_set("gemm_variant", v) and interleaved in one process (A/B rule)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mudpt_amd import capi
+
+SHAPES = [  # (name, M, N, K, epilogue)
+    ("qkv    fwd", 51456, 2304, 768, 0),
+    ("out    fwd", 51456, 768, 768, 5),
+    ("fc     fwd", 51456, 3072, 768, 1),
+    ("proj   fwd", 51456, 768, 3072, 5),
+    ("dgelu  bwd", 51456, 3072, 768, 3),
+    ("dfc    bwd", 51456, 768, 3072, 0),
+    ("dout   bwd", 51456, 768, 768, 0),
+    ("dqkv   bwd", 51456, 768, 2304, 0),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--variants", default="0")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    lib = capi.load()
+    dt, tt = (0, torch.bfloat16) if a.dtype == "bf16" else (1, torch.float16)
+    variants = [int(v) for v in a.variants.split(",")]
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    total = {v: 0.0 for v in variants}
+    for name, M, N, K, epi in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        A = torch.randn(M, K, device="cuda").to(tt)
+        B = (torch.randn(N, K, device="cuda") * K ** -0.5).to(tt)
+        bias = torch.randn(N, device="cuda")
+        f32 = epi in (2, 5)
+        out0 = torch.empty(M, N, device="cuda", dtype=torch.float32 if f32 else tt)
+        out1 = torch.empty(M, N, device="cuda", dtype=tt) if epi == 1 else None
+        aux = torch.randn(M, N, device="cuda").to(torch.float32 if epi == 2 else tt) if epi in (2, 3) else None
+
+        def run():
+            rc = lib.mudpt_gemm(dt, epi, M, N, K, P(A), K, P(B), K, P(bias) if epi != 3 else None, P(out0), N, P(out1), N if out1 is not None else 0,
+                                P(aux), N if aux is not None else 0, 0, 0, None, None)
+            assert rc == 0, lib.mudpt_last_error()
+        best = {v: 1e9 for v in variants}
+        for r in range(a.rounds):
+            for v in variants:
+                capi.check(lib.mudpt_debug_set(b"gemm_variant", v))
+                run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                best[v] = min(best[v], e0.elapsed_time(e1) / a.iters)
+        fl = 2.0 * M * N * K
+        print(f"{name} M={M} N={N} K={K} epi={epi}: " + "  ".join(f"v{v}: {best[v] * 1e3:7.1f} us {fl / best[v] / 1e9:7.1f} TF/s" for v in variants), flush=True)
+        for v in variants:
+            total[v] += best[v]
+    layer_fl = sum(2.0 * M * N * K for _, M, N, K, _ in SHAPES)
+    print("sum over the 8 GEMMs of one block: " + "  ".join(f"v{v}: {total[v] * 1e3:.0f} us ({layer_fl / total[v] / 1e9:.0f} TF/s)" for v in variants))
+
+
+if __name__ == "__main__":
+    main()
