@@ -120,6 +120,10 @@ struct mudpt_model {
     size_t numel[10];
     size_t total = 0;
     float loss_scale = 128.f;  // static, power of two; see mudpt_forward_backward
+    // side stream for the text tower (forks after the prompt learner / head backward, joins before the head /
+    // prompt-learner backward)
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork_b = nullptr, ev_join_b = nullptr;
     // optional HIP-event timing of the MFMA GEMM launches (bench.py's roofline leg)
     bool prof = false;
     std::vector<hipEvent_t> ev;  // pairs
@@ -258,6 +262,8 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
         ALLOC(m->img_inv, B * 4); ALLOC(m->txt_inv, C * 4);
         ALLOC(m->logits, (size_t)B * C * 4); ALLOC(m->dlogits, (size_t)B * C * 4); ALLOC(m->row_loss, B * 4);
         ALLOC(m->dimg, (size_t)B * e * 4); ALLOC(m->dtxt, (size_t)C * e * 4); ALLOC(m->loss, 16);
+        HIP_TRY(hipStreamCreateWithFlags(&m->s2, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&m->ev_fork, &m->ev_join, &m->ev_fork_b, &m->ev_join_b}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
         // row index tables
         std::vector<int> cr(B), pr((size_t)B * n);
         for (int b = 0; b < B; ++b) {
@@ -293,6 +299,9 @@ extern "C" int mudpt_destroy(mudpt_model* m) {
     if (!m) return MUDPT_OK;
     for (void* p : m->allocs) (void)hipFree(p);
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {m->ev_fork, m->ev_join, m->ev_fork_b, m->ev_join_b})
+        if (e) (void)hipEventDestroy(e);
+    if (m->s2) (void)hipStreamDestroy(m->s2);
     delete m;
     return MUDPT_OK;
 }
@@ -510,6 +519,22 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
         TRY(launch_add(m->t2v, Pm + m->off[P_VDEEP], m->vis_deep, (size_t)D1 * n * dv, s));
         TRY(launch_add(m->v2t, Pm + m->off[P_DEEP], m->txt_deep, (size_t)D1 * n * dt, s));
     }
+    // -- text tower, trainers/mudpt.py:142-156: independent of the vision tower once the prompt learner has run, so it
+    // goes to the side stream (enqueued first): its ~200 small launch-latency-bound kernels fill the CUs the big vision
+    // kernels leave idle (tails of the persistent GEMMs, memory-bound LayerNorms) instead of serialising behind them.
+    hipStream_t s2 = m->s2;
+    HIP_TRY(hipEventRecord(m->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(s2, m->ev_fork, 0));
+    HIP_TRY(hipMemcpyAsync(m->txt.a[0].x_in, m->emb_pos, (size_t)C * Lt * dt * 4, hipMemcpyDeviceToDevice, s2));
+    TRY(launch_set_rows(m->txt.a[0].x_in, C, Lt, dt, 1, n, Pm + m->off[P_CTX], m->tpos + dt, s2));
+    for (int i = 0; i < m->txt.layers; ++i) {
+        TRY(block_fwd(m, m->txt, i, C, (i >= 1 && i - 1 < D1) ? m->txt_deep + (size_t)(i - 1) * n * dt : nullptr, s2));
+    }
+    LnFwdArgs lf; lf.x = m->txt.x_last; lf.ldx = dt; lf.row_index = m->eot_rows; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
+    lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = C; lf.d = dt;
+    TRY(launch_ln_fwd(m->dtype, lf, s2));
+    TRY(launch_sgemm(false, false, C, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f, e, nullptr, s2));
+    HIP_TRY(hipEventRecord(m->ev_join, s2));
     // -- vision tower, clip/model.py:526-553
     TRY(launch_patchify(m->dtype, images, m->patches, B, c.image_size, c.patch, s));
     GemmArgs pe; pe.A = m->patches; pe.lda = K0; pe.B = m->conv_w; pe.ldb = K0; pe.M = B * P; pe.N = dv; pe.K = K0; pe.out0 = m->xpre; pe.ldo0 = dv;
@@ -527,17 +552,8 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
     lq.out_f32 = true; lq.mean = m->post_mean; lq.rstd = m->post_rstd; lq.rows = B; lq.d = dv;
     TRY(launch_ln_fwd(m->dtype, lq, s));
     TRY(launch_sgemm(false, false, B, e, dv, 1.f, m->f_ln, dv, m->vproj, e, 0.f, m->img_f, e, nullptr, s));
-    // -- text tower, trainers/mudpt.py:142-156
-    HIP_TRY(hipMemcpyAsync(m->txt.a[0].x_in, m->emb_pos, (size_t)C * Lt * dt * 4, hipMemcpyDeviceToDevice, s));
-    TRY(launch_set_rows(m->txt.a[0].x_in, C, Lt, dt, 1, n, Pm + m->off[P_CTX], m->tpos + dt, s));
-    for (int i = 0; i < m->txt.layers; ++i) {
-        TRY(block_fwd(m, m->txt, i, C, (i >= 1 && i - 1 < D1) ? m->txt_deep + (size_t)(i - 1) * n * dt : nullptr, s));
-    }
-    LnFwdArgs lf; lf.x = m->txt.x_last; lf.ldx = dt; lf.row_index = m->eot_rows; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
-    lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = C; lf.d = dt;
-    TRY(launch_ln_fwd(m->dtype, lf, s));
-    TRY(launch_sgemm(false, false, C, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f, e, nullptr, s));
-    // -- cosine logits, trainers/mudpt.py:178-182
+    // -- cosine logits, trainers/mudpt.py:178-182 (needs both towers)
+    HIP_TRY(hipStreamWaitEvent(s, m->ev_join, 0));
     HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.scale = m->scale; h.logits = m->logits; h.img_n = m->img_n; h.txt_n = m->txt_n;
     h.img_inv = m->img_inv; h.txt_inv = m->txt_inv; h.B = B; h.C = C; h.e = e;
     TRY(launch_head_fwd(h, s));
@@ -578,6 +594,27 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     TRY(launch_head_bwd(h, s));
     HIP_TRY(hipMemcpyAsync(loss, m->loss, 4, hipMemcpyDeviceToDevice, s));
 
+    // -- text tower backward, on the side stream (enqueued first; joins before the prompt-learner backward).  It only
+    // reads dtxt / its own activations and only writes its own buffers, d_txt_deep and the ctx slice of the gradient bucket.
+    hipStream_t s2 = m->s2;
+    HIP_TRY(hipEventRecord(m->ev_fork_b, s));
+    HIP_TRY(hipStreamWaitEvent(s2, m->ev_fork_b, 0));
+    Tower& X = m->txt;
+    TRY(launch_sgemm(false, true, C, dt, e, 1.f, m->dtxt, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s2));
+    HIP_TRY(hipMemsetAsync(X.dx, 0, (size_t)C * Lt * dt * 4, s2));
+    HIP_TRY(hipMemsetAsync(X.dx_lp, 0, (size_t)C * Lt * dt * 2, s2));
+    LnBwdArgs bf; bf.dy = m->dt_ln; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.x_last; bf.ldx = dt; bf.row_index = m->eot_rows; bf.mean = m->fin_mean; bf.rstd = m->fin_rstd;
+    bf.gamma = m->ln_fin_g; bf.dx = X.dx; bf.lddx = dt; bf.dx_lp = X.dx_lp; bf.lddx_lp = dt; bf.rows = C; bf.d = dt;
+    TRY(launch_ln_bwd(m->dtype, bf, s2));
+    for (int i = X.layers - 1; i >= 0; --i) {
+        TRY(block_bwd(m, X, i, C, s2));
+        if (i >= 1 && i - 1 < D1)
+            TRY(launch_reduce_rows(m->dtype, X.dx, X.dx_lp, C, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, unscale, s2));
+    }
+    // d ctx (text side): rows 1..n of the first block's input, summed over the class prompts
+    TRY(launch_reduce_rows(m->dtype, X.dx, nullptr, C, Lt, dt, 1, n, G + m->off[P_CTX], false, true, unscale, s2));
+    HIP_TRY(hipEventRecord(m->ev_join_b, s2));
+
     // -- vision tower backward
     Tower& V = m->vis;
     TRY(launch_sgemm(false, true, B, dv, e, 1.f, m->dimg, e, m->vproj, e, 0.f, m->df_ln, dv, nullptr, s));
@@ -597,23 +634,8 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     TRY(launch_ln_bwd(m->dtype, bp, s));
     TRY(launch_reduce_rows(m->dtype, V.dx, nullptr, B, Lv, dv, Lv - n, n, m->d_vprompt0, false, false, unscale, s));
 
-    // -- text tower backward
-    Tower& X = m->txt;
-    TRY(launch_sgemm(false, true, C, dt, e, 1.f, m->dtxt, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s));
-    HIP_TRY(hipMemsetAsync(X.dx, 0, (size_t)C * Lt * dt * 4, s));
-    HIP_TRY(hipMemsetAsync(X.dx_lp, 0, (size_t)C * Lt * dt * 2, s));
-    LnBwdArgs bf; bf.dy = m->dt_ln; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.x_last; bf.ldx = dt; bf.row_index = m->eot_rows; bf.mean = m->fin_mean; bf.rstd = m->fin_rstd;
-    bf.gamma = m->ln_fin_g; bf.dx = X.dx; bf.lddx = dt; bf.dx_lp = X.dx_lp; bf.lddx_lp = dt; bf.rows = C; bf.d = dt;
-    TRY(launch_ln_bwd(m->dtype, bf, s));
-    for (int i = X.layers - 1; i >= 0; --i) {
-        TRY(block_bwd(m, X, i, C, s));
-        if (i >= 1 && i - 1 < D1)
-            TRY(launch_reduce_rows(m->dtype, X.dx, X.dx_lp, C, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, unscale, s));
-    }
-    // d ctx (text side): rows 1..n of the first block's input, summed over the class prompts
-    TRY(launch_reduce_rows(m->dtype, X.dx, nullptr, C, Lt, dt, 1, n, G + m->off[P_CTX], false, true, unscale, s));
-
-    // -- prompt learner backward (fp32, tiny)
+    // -- prompt learner backward (fp32, tiny): needs both towers' prompt gradients
+    HIP_TRY(hipStreamWaitEvent(s, m->ev_join_b, 0));
     // visual_ctx and shared = embed_projection(ctx) both receive d_vprompt0 (clip/model.py:534)
     TRY(launch_add(G + m->off[P_VCTX], m->d_vprompt0, G + m->off[P_VCTX], (size_t)n * dv, s));
     TRY(launch_sgemm(true, false, dv, dt, n, 1.f, m->d_vprompt0, dv, Pm + m->off[P_CTX], dt, 1.f, G + m->off[P_EW], dt, nullptr, s));
