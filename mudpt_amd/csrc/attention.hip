@@ -53,6 +53,29 @@ struct Attn {
             *(vec8*)(img + row * RS + ch * 8) = v;
         }
     }
+    // Two images at once, ALL global loads issued before the first LDS store (one HBM round trip per workgroup instead of
+    // one per chunk).  CH = chunks per thread per image = Lp * 8 / nthreads (exact for nthreads = 2 * Lp).
+    template <int CH>
+    __device__ static inline void stage2(elem* img0, const elem* src0, size_t ld0, elem* img1, const elem* src1, size_t ld1, int L,
+                                         int tid, int nthreads) {
+        vec8 v0[CH], v1[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int idx = tid + k * nthreads, row = idx >> 3, ch = idx & 7;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v0[k][i] = (elem)0.f; v1[k][i] = (elem)0.f; }
+            if (row < L) {
+                v0[k] = *(const vec8*)(src0 + (size_t)row * ld0 + ch * 8);
+                v1[k] = *(const vec8*)(src1 + (size_t)row * ld1 + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int idx = tid + k * nthreads, row = idx >> 3, ch = idx & 7;
+            *(vec8*)(img0 + row * RS + ch * 8) = v0[k];
+            *(vec8*)(img1 + row * RS + ch * 8) = v1[k];
+        }
+    }
     // 16 x 32 row fragment (A or B operand whose k runs along the image's columns): rows row0 + (lane & 15)
     __device__ static inline vec8 rows(const elem* img, int row0, int ks, int lane) {
         return *(const vec8*)(img + (row0 + (lane & 15)) * RS + ks * 32 + (lane >> 4) * 8);
@@ -109,82 +132,95 @@ __device__ inline float group_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// One 16-query block of one (sequence, head) pair: scores, softmax, P.V, store.  q0 / q1 = this lane's Q fragments.
+template <typename T, int NC, bool CAUSAL>
+__device__ inline void fwd_qblock(const AttnArgs& p, const typename T::elem* Ks, const typename T::elem* Vs, const float* kmask, int pair,
+                                  int qb, typename T::vec8 q0, typename T::vec8 q1, int lane) {
+    using A = Attn<T>;
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    constexpr int Lp = NC * 32;
+    const int g = lane >> 4, c = lane & 15, L = p.L, HD = p.H * 64;
+    const int q = qb * 16 + c;
+    const int nkc = CAUSAL ? (qb >> 1) + 1 : NC;  // 32-key chunks that hold a visible key
+
+    f32x4 S[2 * NC];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NC; ++kt) {
+        S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kt < 2 * nkc) {
+            S[kt] = *(const f32x4*)(kmask + kt * 16 + 4 * g);  // padding keys start (and stay) at -inf: no per-element mask
+            S[kt] = T::mfma16(A::rows(Ks, kt * 16, 0, lane), q0, S[kt]);
+            S[kt] = T::mfma16(A::rows(Ks, kt * 16, 1, lane), q1, S[kt]);
+            if constexpr (CAUSAL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + 4 * g + r > q) S[kt][r] = -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, S[kt][r]);
+        }
+    }
+    m = group_max(m);
+    const float nm = -m * SC;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NC; ++kt)
+        if (kt < 2 * nkc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][r], SC, nm));
+                S[kt][r] = e;
+                l += e;
+            }
+        }
+    l = group_sum(l);
+
+    f32x4 O[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < NC; ++kc)
+        if (kc < nkc) {
+            // keep each chunk's transposed V reads next to their MFMAs: they do not depend on the softmax, and hoisted
+            // above it all 28 fragments (112 VGPRs) would be live at once
+            __builtin_amdgcn_sched_barrier(0);
+            const vec8 pb = A::pack2(S[2 * kc], S[2 * kc + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) O[dt] = T::mfma16(A::cols(Vs, kc * 32, dt * 16, lane), pb, O[dt]);
+        }
+    const int b = pair / p.H, hd = pair - b * p.H;
+    if (q < L) A::store_t((elem*)p.out + ((size_t)b * L + q) * HD + hd * 64, O, 1.f / l, lane);
+    if (g == 0 && p.lse) p.lse[(size_t)pair * Lp + q] = q < L ? m * 0.125f + __logf(l) : 0.f;
+}
+
+// One workgroup per (sequence, head) pair, two of them per CU.  (A persistent variant that prefetched the next pair's
+// K / V into registers was measured 35 % SLOWER: the extra 32 VGPRs push the 16-row block over 128 registers.)
 template <typename T, int NC, bool CAUSAL>
 __global__ __launch_bounds__(NC * 64) void attn_fwd_kernel(AttnArgs p) {
     using A = Attn<T>;
     using elem = typename T::elem;
-    using vec8 = typename T::vec8;
     constexpr int Lp = NC * 32, NT = NC * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     elem* Ks = (elem*)smem;      // [Lp][RS]
     elem* Vs = Ks + Lp * RS;     // [Lp][RS]
+    float* kmask = (float*)(Vs + Lp * RS);  // [Lp] 0 for real keys, -inf for padding: the score accumulators' initial value
 
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H;
+    const int pair = blockIdx.x, b = pair / p.H, hd = pair - b * p.H;
     const int HD = p.H * 64, L = p.L;
     const size_t ld = (size_t)3 * HD;
     const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
 
-    A::stage(Ks, base + HD, ld, L, Lp, tid, NT);
-    A::stage(Vs, base + 2 * HD, ld, L, Lp, tid, NT);
+    A::template stage2<4>(Ks, base + HD, ld, Vs, base + 2 * HD, ld, L, tid, NT);
+    for (int i = tid; i < Lp; i += NT) kmask[i] = i < L ? 0.f : -INFINITY;
     __syncthreads();
 
     const int nqb = (L + 15) >> 4;
-    for (int qb = wave; qb < nqb; qb += NC) {
-        const int q = qb * 16 + c;
-        const vec8 q0 = A::grow(base, ld, q, L, 0, lane), q1 = A::grow(base, ld, q, L, 1, lane);
-        const int nkc = CAUSAL ? (qb >> 1) + 1 : NC;  // 32-key chunks that hold a visible key
-
-        f32x4 S[2 * NC];
-        float m = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 2 * NC; ++kt) {
-            S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kt < 2 * nkc) {
-                S[kt] = T::mfma16(A::rows(Ks, kt * 16, 0, lane), q0, S[kt]);
-                S[kt] = T::mfma16(A::rows(Ks, kt * 16, 1, lane), q1, S[kt]);
-                if (kt * 16 + 16 > L || (CAUSAL && kt >= qb)) {  // tile touches the padding or the diagonal
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kt * 16 + 4 * g + r;
-                        if (key >= L || (CAUSAL && key > q)) S[kt][r] = -INFINITY;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) m = fmaxf(m, S[kt][r]);
-            }
-        }
-        m = group_max(m);
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2 * NC; ++kt)
-            if (kt < 2 * nkc) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f((S[kt][r] - m) * SC);
-                    S[kt][r] = e;
-                    l += e;
-                }
-            }
-        l = group_sum(l);
-
-        f32x4 O[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kc = 0; kc < NC; ++kc)
-            if (kc < nkc) {
-                // keep each chunk's transposed V reads next to their MFMAs: they do not depend on the softmax, and hoisted
-                // above it all 28 fragments (112 VGPRs) would be live at once
-                __builtin_amdgcn_sched_barrier(0);
-                const vec8 pb = A::pack2(S[2 * kc], S[2 * kc + 1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) O[dt] = T::mfma16(A::cols(Vs, kc * 32, dt * 16, lane), pb, O[dt]);
-            }
-        if (q < L) A::store_t((elem*)p.out + ((size_t)b * L + q) * HD + hd * 64, O, 1.f / l, lane);
-        if (g == 0 && p.lse) p.lse[((size_t)b * p.H + hd) * Lp + q] = q < L ? m * 0.125f + __logf(l) : 0.f;
-    }
+    for (int qb = wave; qb < nqb; qb += NC)
+        fwd_qblock<T, NC, CAUSAL>(p, Ks, Vs, kmask, pair, qb, A::grow(base, ld, qb * 16 + c, L, 0, lane), A::grow(base, ld, qb * 16 + c, L, 1, lane), lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -199,6 +235,7 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     elem* Ks = (elem*)smem;
     elem* Vs = Ks + Lp * RS;
+    float* kmask = (float*)(Vs + Lp * RS);  // [Lp] 0 / -inf, see the forward kernel
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,8 +246,8 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
     const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
     const elem* Of = (const elem*)fwd_out + (size_t)b * L * HD + hd * 64;
 
-    A::stage(Ks, base + HD, ld, L, Lp, tid, NT);
-    A::stage(Vs, base + 2 * HD, ld, L, Lp, tid, NT);
+    A::template stage2<4>(Ks, base + HD, ld, Vs, base + 2 * HD, ld, L, tid, NT);
+    for (int i = tid; i < Lp; i += NT) kmask[i] = i < L ? 0.f : -INFINITY;
     __syncthreads();
 
     const int nqb = (L + 15) >> 4;
@@ -237,24 +274,24 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int kt = 2 * kc + t;
-                f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {-delta, -delta, -delta, -delta};
+                f32x4 S = *(const f32x4*)(kmask + kt * 16 + 4 * g), dP = {-delta, -delta, -delta, -delta};
                 S = T::mfma16(A::rows(Ks, kt * 16, 0, lane), q0, S);
                 S = T::mfma16(A::rows(Ks, kt * 16, 1, lane), q1, S);
                 dP = T::mfma16(A::rows(Vs, kt * 16, 0, lane), g0, dP);
                 dP = T::mfma16(A::rows(Vs, kt * 16, 1, lane), g1, dP);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + 4 * g + r;
-                    const bool dead = key >= L || q >= L || (CAUSAL && key > q);
-                    const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(S[r] * SC + nlse);
-                    ds[t][r] = pr * dP[r] * 0.125f;  // dS^T, already times 1 / sqrt(d); delta entered through dP's initial value
+                    // padding keys: S = -inf -> p = 0; padding queries (q >= L) are never stored
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nlse));
+                    if (CAUSAL && kt * 16 + 4 * g + r > q) pr = 0.f;
+                    ds[t][r] = pr * dP[r];  // dS^T up to the 1 / sqrt(d) applied at the store; delta entered through dP's initial value
                 }
             }
             const vec8 db = A::pack2(ds[0], ds[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dQ[dt] = T::mfma16(A::cols(Ks, kc * 32, dt * 16, lane), db, dQ[dt]);
         }
-        if (q < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + q) * ld + hd * 64, dQ, 1.f, lane);
+        if (q < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + q) * ld + hd * 64, dQ, 0.125f, lane);
     }
 }
 
@@ -281,11 +318,10 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
     const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
     const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
 
-    A::stage(Qs, base, ld, L, Lp, tid, NT);
-    A::stage(Gs, dO, (size_t)HD, L, Lp, tid, NT);
+    A::template stage2<4>(Qs, base, ld, Gs, dO, (size_t)HD, L, tid, NT);
     for (int i = tid; i < Lp; i += NT) {
         const size_t stat = ((size_t)b * p.H + hd) * Lp + i;
-        lse_s[i] = i < L ? -p.lse[stat] * LOG2E : 0.f;  // rows >= L were never written by the forward / dq pass
+        lse_s[i] = i < L ? -p.lse[stat] * LOG2E : -INFINITY;  // padding queries: p = exp2(. - inf) = 0, no per-element mask
         del_s[i] = i < L ? p.delta[stat] : 0.f;
     }
     __syncthreads();
@@ -313,11 +349,11 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
                 dP = T::mfma16(A::rows(Gs, qt * 16, 1, lane), v1, dP);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = qt * 16 + 4 * g + r;
-                    const bool dead = key >= L || q >= L || (CAUSAL && key > q);
-                    const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(S[r] * SC + nl[r]);
+                    // padding queries have nl = -inf -> p = 0; padding keys (key >= L) are whole lanes that are never stored
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nl[r]));
+                    if (CAUSAL && key > qt * 16 + 4 * g + r) pr = 0.f;
                     P[t][r] = pr;
-                    dS[t][r] = pr * dP[r] * 0.125f;
+                    dS[t][r] = pr * dP[r];  // 1 / sqrt(d) applied at the store
                 }
             }
             const vec8 pb = A::pack2(P[0], P[1]), db = A::pack2(dS[0], dS[1]);
@@ -329,7 +365,7 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
         }
         if (key < L) {
             elem* ok = (elem*)p.dqkv + ((size_t)b * L + key) * ld + HD + hd * 64;
-            A::store_t(ok, dK, 1.f, lane);
+            A::store_t(ok, dK, 0.125f, lane);
             A::store_t(ok + HD, dV, 1.f, lane);
         }
     }
@@ -355,7 +391,7 @@ static int set_lds(K kern, int bytes) {
 
 template <typename T, int NC, bool CAUSAL>
 static int fwd_cfg(const AttnArgs& a, hipStream_t s) {
-    constexpr int lds = 2 * NC * 32 * RS * 2;
+    constexpr int lds = 2 * NC * 32 * RS * 2 + NC * 32 * 4;
     auto kern = attn_fwd_kernel<T, NC, CAUSAL>;
     static bool once = false;
     if (!once) { if (int e = set_lds(kern, lds)) return e; once = true; }
@@ -366,8 +402,8 @@ static int fwd_cfg(const AttnArgs& a, hipStream_t s) {
 
 template <typename T, int NC, bool CAUSAL>
 static int bwd_cfg(const AttnArgs& a, hipStream_t s) {
-    constexpr int lds1 = 2 * NC * 32 * RS * 2;
-    constexpr int lds2 = lds1 + 2 * NC * 32 * 4;
+    constexpr int lds1 = 2 * NC * 32 * RS * 2 + NC * 32 * 4;
+    constexpr int lds2 = 2 * NC * 32 * RS * 2 + 2 * NC * 32 * 4;
     auto k1 = attn_bwd_dq_kernel<T, NC, CAUSAL>;
     auto k2 = attn_bwd_dkv_kernel<T, NC, CAUSAL>;
     static bool once = false;

@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(float* __restrict__ sr
     if (live)
         for (int b = b0; b < b1; ++b) {
             const size_t o = ((size_t)b * L + row0 + i) * d + c;
-            acc += src[o];
+            acc += src ? src[o] : (float)src_lp[o];  // src == null: the gradient stream lives in T only
             if (zero_src) {
-                src[o] = 0.f;
+                if (src) src[o] = 0.f;
                 if (src_lp) src_lp[o] = (typename T::elem)0.f;
             }
         }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(float* __restrict__ sr
 
 int launch_reduce_rows(int dtype, float* src, void* src_lp, int B, int L, int d, int row0, int n, float* out, bool zero_src,
                        bool accumulate, float scale, hipStream_t s) {
-    ARG_CHECK(src && out && B > 0 && n > 0 && row0 >= 0 && row0 + n <= L, "reduce_rows: bad arguments");
+    ARG_CHECK((src || src_lp) && out && B > 0 && n > 0 && row0 >= 0 && row0 + n <= L, "reduce_rows: bad arguments");
     const int grid = (n * d + 31) / 32;
     if (dtype == DT_BF16)
         hipLaunchKernelGGL(reduce_rows_kernel<BF16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)src_lp, B, L, d, row0, n, out, zero_src, accumulate, scale);

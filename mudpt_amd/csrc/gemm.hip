@@ -209,6 +209,14 @@ static int launch_t(int epi, const GemmArgs& a, hipStream_t s) {
     return MUDPT_ERR_ARG;
 }
 
+// default dispatch: the persistent ping-pong kernel takes the big GEMMs whose epilogue needs no operand load besides bias / u
+bool gemm_uses_pp(int epi, const GemmArgs& a) {
+    const bool pp_epi = epi == EPI_STORE || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32;
+    const int v = g_gemm_variant & 0xff;
+    return (v == 0 || v == 3) && pp_epi && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
+           (epi != EPI_GELU_BWD || a.ldaux % 8 == 0);
+}
+
 int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     ARG_CHECK(a.A && a.B && a.out0, "gemm: null operand");
     ARG_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -223,11 +231,7 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     GemmArgs b = a;
     if (g_gemm_variant & 0x100) b.flags |= 1;
     // default: the persistent ping-pong kernel for the big GEMMs whose epilogue needs no operand load besides bias / u
-    const bool pp_epi = epi == EPI_STORE || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32;
-    const int v = g_gemm_variant & 0xff;
-    if ((v == 0 || v == 3) && pp_epi && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
-        (epi != EPI_GELU_BWD || a.ldaux % 8 == 0))
-        return launch_gemm_pp(dtype, epi, b, s);
+    if (gemm_uses_pp(epi, a)) return launch_gemm_pp(dtype, epi, b, s);
     if (dtype == DT_BF16) return launch_t<BF16>(epi, b, s);
     if (dtype == DT_F16) return launch_t<F16>(epi, b, s);
     set_error("gemm: unknown dtype %d", dtype);

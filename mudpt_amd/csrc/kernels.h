@@ -33,6 +33,7 @@ struct GemmArgs {
 };
 int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s);
 extern int g_gemm_variant;  // tuning knob, see gemm.hip
+bool gemm_uses_pp(int epi, const GemmArgs& a);  // true if launch_gemm dispatches to gemm_pp_kernel
 int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s);  // persistent 256x256 ping-pong kernel (gemm_pp.hip)
 
 // ------------------------------------------------------------------------------------------------
@@ -61,7 +62,8 @@ struct LnBwdArgs {
     const int* row_index = nullptr;
     const float* mean = nullptr; const float* rstd = nullptr; const float* gamma = nullptr;
     const float* dres = nullptr; int lddres = 0;  // optional residual gradient added to the result (same row map as out)
-    float* dx = nullptr; int lddx = 0;        // fp32 result rows, written at row_index[r] (scatter) or r
+    const void* dres_lp = nullptr;                // ... or the same in T (stride lddres) when the gradient stream is kept in T
+    float* dx = nullptr; int lddx = 0;        // fp32 result rows, written at row_index[r] (scatter) or r; may be null if dx_lp is set
     void* dx_lp = nullptr; int lddx_lp = 0;   // optional T copy of the result
     int rows = 0, d = 0;
     bool by_token = false;  // dy / mean / rstd rows are indexed by the token row (row_index[r]) instead of r

@@ -118,7 +118,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) dx[j] = rstd * (g[k][j] - c1 - xh[k][j] * c2);
             if (p.dres) dx += ((const f32x4*)(p.dres + t * p.lddres))[i];
-            ((f32x4*)(p.dx + t * p.lddx))[i] = dx;
+            if (p.dres_lp) {  // the gradient stream itself is kept in T (bf16 mode): no fp32 copy to read or write
+                const typename T::vec4 rv = ((const typename T::vec4*)((const elem*)p.dres_lp + t * p.lddres))[i];
+                dx += f32x4{(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]};
+            }
+            if (p.dx) ((f32x4*)(p.dx + t * p.lddx))[i] = dx;
             if (p.dx_lp) {
                 typename T::vec4 o = {(elem)dx[0], (elem)dx[1], (elem)dx[2], (elem)dx[3]};
                 ((typename T::vec4*)((elem*)p.dx_lp + t * p.lddx_lp))[i] = o;
@@ -147,7 +151,8 @@ int launch_ln_fwd(int dtype, const LnFwdArgs& a, hipStream_t s) {
 }
 
 int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s) {
-    ARG_CHECK(a.dy && a.x && a.mean && a.rstd && a.gamma && a.dx, "ln_bwd: null operand");
+    ARG_CHECK(a.dy && a.x && a.mean && a.rstd && a.gamma && (a.dx || a.dx_lp), "ln_bwd: null operand");
+    ARG_CHECK(!(a.dres && a.dres_lp), "ln_bwd: dres and dres_lp are exclusive");
     ARG_CHECK(a.rows > 0 && a.d > 0 && a.d % 4 == 0 && a.d <= 256 * LN_MAXV, "ln_bwd: bad shape rows=%d d=%d", a.rows, a.d);
     ARG_CHECK(a.ldx % 4 == 0 && a.lddy % 4 == 0 && a.lddx % 4 == 0, "ln_bwd: strides must be multiples of 4");
     const dim3 grid((a.rows + 3) / 4), block(256);

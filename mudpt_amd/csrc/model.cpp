@@ -120,6 +120,9 @@ struct mudpt_model {
     size_t numel[10];
     size_t total = 0;
     float loss_scale = 128.f;  // static, power of two; see mudpt_forward_backward
+    // bf16 mode keeps the gradient of the residual stream in T only (the fp32 copy costs 237 MB of HBM traffic per
+    // LayerNorm backward); fp16 mode -- the parity configuration -- keeps it in fp32.  mudpt_debug_set("lp_grad") overrides.
+    bool lp_grad = false;
     // side stream for the text tower (forks after the prompt learner / head backward, joins before the head /
     // prompt-learner backward)
     hipStream_t s2 = nullptr;
@@ -134,7 +137,9 @@ struct mudpt_model {
 // Every MFMA GEMM of the path goes through here; with profiling on, the launch is bracketed by HIP events on
 // the launch stream and its algorithmic FLOPs (2 M N K) are recorded.
 static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s) {
-    if (!m->prof) return launch_gemm(m->dtype, epi, a, s);
+    // only the dominant kernel is bracketed: gemm_pp_kernel launches (the vision tower's big GEMMs, main stream).  The text
+    // tower's small GEMMs run on the side stream, where an event pair would mostly measure queueing behind the other stream.
+    if (!m->prof || !gemm_uses_pp(epi, a)) return launch_gemm(m->dtype, epi, a, s);
     if (m->ev_used + 2 > m->ev.size()) {
         for (int i = 0; i < 512; ++i) {
             hipEvent_t e;
@@ -149,6 +154,8 @@ static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s) 
     m->ev_flop.push_back(2.0 * a.M * a.N * a.K);
     return rc;
 }
+
+static bool g_lp_grad_default = true;
 
 static const char* kParamNames[10] = {
     "mudpt_prompt_learner.ctx",
@@ -236,6 +243,7 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     mudpt_model* m = new mudpt_model();
     m->cfg = *c;
     m->dtype = c->dtype;
+    m->lp_grad = (c->dtype == MUDPT_BF16) && g_lp_grad_default;
     const int dv = c->v_width, dt = c->t_width, e = c->embed_dim, n = c->n_ctx, D1 = c->depth - 1, B = c->max_batch, C = c->n_cls;
     auto fail = [&](int code) { mudpt_destroy(m); return code; };
     if (int r = alloc_tower(m, m->vis, dv, c->v_layers, c->v_heads, Lv, B, false, Lv - n)) return fail(r);
@@ -491,8 +499,9 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
     TRY(gemm_call(m, EPI_GELU_BWD, g1, s));
     GemmArgs g2; g2.A = t.g; g2.lda = 4 * d; g2.B = w.w_fc_t; g2.ldb = 4 * d; g2.M = M; g2.N = d; g2.K = 4 * d; g2.out0 = t.h; g2.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g2, s));
-    LnBwdArgs b2; b2.dy = t.h; b2.lddy = d; b2.x = a.x_mid; b2.ldx = d; b2.mean = a.mean2; b2.rstd = a.rstd2; b2.gamma = w.ln2_g; b2.dres = t.dx; b2.lddres = d;
-    b2.dx = t.dx; b2.lddx = d; b2.dx_lp = t.dx_lp; b2.lddx_lp = d; b2.rows = M; b2.d = d;
+    LnBwdArgs b2; b2.dy = t.h; b2.lddy = d; b2.x = a.x_mid; b2.ldx = d; b2.mean = a.mean2; b2.rstd = a.rstd2; b2.gamma = w.ln2_g; b2.lddres = d;
+    if (m->lp_grad) b2.dres_lp = t.dx_lp; else { b2.dres = t.dx; b2.dx = t.dx; }
+    b2.lddx = d; b2.dx_lp = t.dx_lp; b2.lddx_lp = d; b2.rows = M; b2.d = d;
     TRY(launch_ln_bwd(dt, b2, s));
     GemmArgs g3; g3.A = t.dx_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = M; g3.N = d; g3.K = d; g3.out0 = t.dattn; g3.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g3, s));
@@ -500,8 +509,9 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
     TRY(launch_attn_bwd(dt, at, s));
     GemmArgs g4; g4.A = t.dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 3 * d; g4.out0 = t.h; g4.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g4, s));
-    LnBwdArgs b1; b1.dy = t.h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.dres = t.dx; b1.lddres = d;
-    b1.dx = t.dx; b1.lddx = d; b1.dx_lp = t.dx_lp; b1.lddx_lp = d; b1.rows = M; b1.d = d;
+    LnBwdArgs b1; b1.dy = t.h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.lddres = d;
+    if (m->lp_grad) b1.dres_lp = t.dx_lp; else { b1.dres = t.dx; b1.dx = t.dx; }
+    b1.lddx = d; b1.dx_lp = t.dx_lp; b1.lddx_lp = d; b1.rows = M; b1.d = d;
     TRY(launch_ln_bwd(dt, b1, s));
     return MUDPT_OK;
 }
@@ -601,35 +611,35 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     HIP_TRY(hipStreamWaitEvent(s2, m->ev_fork_b, 0));
     Tower& X = m->txt;
     TRY(launch_sgemm(false, true, C, dt, e, 1.f, m->dtxt, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s2));
-    HIP_TRY(hipMemsetAsync(X.dx, 0, (size_t)C * Lt * dt * 4, s2));
+    if (!m->lp_grad) HIP_TRY(hipMemsetAsync(X.dx, 0, (size_t)C * Lt * dt * 4, s2));
     HIP_TRY(hipMemsetAsync(X.dx_lp, 0, (size_t)C * Lt * dt * 2, s2));
     LnBwdArgs bf; bf.dy = m->dt_ln; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.x_last; bf.ldx = dt; bf.row_index = m->eot_rows; bf.mean = m->fin_mean; bf.rstd = m->fin_rstd;
-    bf.gamma = m->ln_fin_g; bf.dx = X.dx; bf.lddx = dt; bf.dx_lp = X.dx_lp; bf.lddx_lp = dt; bf.rows = C; bf.d = dt;
+    bf.gamma = m->ln_fin_g; bf.dx = m->lp_grad ? nullptr : X.dx; bf.lddx = dt; bf.dx_lp = X.dx_lp; bf.lddx_lp = dt; bf.rows = C; bf.d = dt;
     TRY(launch_ln_bwd(m->dtype, bf, s2));
     for (int i = X.layers - 1; i >= 0; --i) {
         TRY(block_bwd(m, X, i, C, s2));
         if (i >= 1 && i - 1 < D1)
-            TRY(launch_reduce_rows(m->dtype, X.dx, X.dx_lp, C, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, unscale, s2));
+            TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, X.dx_lp, C, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, unscale, s2));
     }
     // d ctx (text side): rows 1..n of the first block's input, summed over the class prompts
-    TRY(launch_reduce_rows(m->dtype, X.dx, nullptr, C, Lt, dt, 1, n, G + m->off[P_CTX], false, true, unscale, s2));
+    TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, m->lp_grad ? X.dx_lp : nullptr, C, Lt, dt, 1, n, G + m->off[P_CTX], false, true, unscale, s2));
     HIP_TRY(hipEventRecord(m->ev_join_b, s2));
 
     // -- vision tower backward
     Tower& V = m->vis;
     TRY(launch_sgemm(false, true, B, dv, e, 1.f, m->dimg, e, m->vproj, e, 0.f, m->df_ln, dv, nullptr, s));
-    HIP_TRY(hipMemsetAsync(V.dx, 0, (size_t)B * Lv * dv * 4, s));
+    if (!m->lp_grad) HIP_TRY(hipMemsetAsync(V.dx, 0, (size_t)B * Lv * dv * 4, s));
     HIP_TRY(hipMemsetAsync(V.dx_lp, 0, (size_t)B * Lv * dv * 2, s));
     LnBwdArgs bq; bq.dy = m->df_ln; bq.lddy = dv; bq.dy_f32 = true; bq.x = V.x_last; bq.ldx = dv; bq.row_index = m->cls_rows; bq.mean = m->post_mean; bq.rstd = m->post_rstd;
-    bq.gamma = m->ln_post_g; bq.dx = V.dx; bq.lddx = dv; bq.dx_lp = V.dx_lp; bq.lddx_lp = dv; bq.rows = B; bq.d = dv;
+    bq.gamma = m->ln_post_g; bq.dx = m->lp_grad ? nullptr : V.dx; bq.lddx = dv; bq.dx_lp = V.dx_lp; bq.lddx_lp = dv; bq.rows = B; bq.d = dv;
     TRY(launch_ln_bwd(m->dtype, bq, s));
     for (int i = V.layers - 1; i >= 0; --i) {
         TRY(block_bwd(m, V, i, B, s));
         if (i >= 1 && i - 1 < D1)  // backward of the splice: prompt rows feed d(vis_deep[i-1]); the overwritten rows get no gradient
-            TRY(launch_reduce_rows(m->dtype, V.dx, V.dx_lp, B, Lv, dv, Lv - n, n, m->d_vis_deep + (size_t)(i - 1) * n * dv, true, false, unscale, s));
+            TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : V.dx, V.dx_lp, B, Lv, dv, Lv - n, n, m->d_vis_deep + (size_t)(i - 1) * n * dv, true, false, unscale, s));
     }
     // ln_pre backward on the prompt rows only (patch / CLS rows have no trainable ancestor), in place
-    LnBwdArgs bp; bp.dy = V.dx; bp.lddy = dv; bp.dy_f32 = true; bp.x = m->xpre; bp.ldx = dv; bp.row_index = m->vprompt_rows; bp.mean = m->pre_mean; bp.rstd = m->pre_rstd;
+    LnBwdArgs bp; bp.dy = m->lp_grad ? (const void*)V.dx_lp : (const void*)V.dx; bp.lddy = dv; bp.dy_f32 = !m->lp_grad; bp.x = m->xpre; bp.ldx = dv; bp.row_index = m->vprompt_rows; bp.mean = m->pre_mean; bp.rstd = m->pre_rstd;
     bp.gamma = m->ln_pre_g; bp.dx = V.dx; bp.lddx = dv; bp.rows = B * n; bp.d = dv; bp.by_token = true;
     TRY(launch_ln_bwd(m->dtype, bp, s));
     TRY(launch_reduce_rows(m->dtype, V.dx, nullptr, B, Lv, dv, Lv - n, n, m->d_vprompt0, false, false, unscale, s));
@@ -683,6 +693,7 @@ extern "C" int mudpt_set_loss_scale(mudpt_model* m, float loss_scale) {
 extern "C" int mudpt_debug_set(const char* name, int32_t value) {
     ARG_CHECK(name, "debug_set: null name");
     if (!strcmp(name, "gemm_variant")) { g_gemm_variant = value; return MUDPT_OK; }
+    if (!strcmp(name, "lp_grad")) { g_lp_grad_default = value != 0; return MUDPT_OK; }  // applies to models created afterwards
     set_error("debug_set: unknown knob '%s'", name);
     return MUDPT_ERR_ARG;
 }

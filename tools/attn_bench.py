@@ -1,0 +1,47 @@
+"""Attention micro-benchmark through the C ABI (GPU box): vision shape B=256, L=201, H=12 and text 11 x 77 x 8."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mudpt_amd import capi
+
+
+def main():
+    lib = capi.load()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    for name, B, L, H, causal in (("vision", 256, 201, 12, 0), ("text", 11, 77, 8, 1), ("text1000", 1000, 77, 8, 1)):
+        Lp = lib.mudpt_attention_padded_len(L)
+        qkv = torch.randn(B, L, 3 * H * 64, device="cuda").to(torch.bfloat16)
+        dout = torch.randn(B, L, H * 64, device="cuda").to(torch.bfloat16)
+        out = torch.empty(B, L, H * 64, device="cuda", dtype=torch.bfloat16)
+        dqkv = torch.empty_like(qkv)
+        lse = torch.zeros(B, H, Lp, device="cuda")
+        delta = torch.zeros(B, H, Lp, device="cuda")
+
+        def fwd():
+            assert lib.mudpt_attention_fwd(0, P(qkv), P(out), P(lse), B, L, H, causal, None) == 0
+
+        def bwd():
+            assert lib.mudpt_attention_bwd(0, P(qkv), P(out), P(dout), P(lse), P(delta), P(dqkv), B, L, H, causal, None) == 0
+        res = []
+        for fn in (fwd, bwd):
+            fn()
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 10)
+            res.append(best)
+        fl = 4.0 * B * H * L * L * 64
+        print(f"{name}: fwd {res[0] * 1e3:7.1f} us ({fl / res[0] / 1e9:6.1f} TF/s)   bwd (dq + dkv) {res[1] * 1e3:7.1f} us ({2.5 * fl / res[1] / 1e9:6.1f} TF/s algorithmic)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
