@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--graph", action="store_true", help="replay forward+backward from a captured hipGraph (implies --no-profile)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,8 +102,22 @@ def main():
     labels = torch.randint(0, C, (B,), generator=g).cuda()
     lr = 0.0025  # configs/trainers/MuDPT/vit_b16_bz4_ep10_nctx4_depth9.yaml OPTIM.LR
 
+    graph = None
+    if args.graph:
+        args.no_profile = True
+        for _ in range(2):  # first-use initialisation (function attributes, allocations) must happen outside the capture
+            model.forward_backward(images, labels, grad_scale=1.0 / world)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            model.forward_backward(images, labels, grad_scale=1.0 / world)
+
     def step():
-        loss = model.forward_backward(images, labels, grad_scale=1.0 / world)
+        if graph is not None:
+            graph.replay()
+            loss = model._loss[0]
+        else:
+            loss = model.forward_backward(images, labels, grad_scale=1.0 / world)
         if dist is not None:
             dist.all_reduce(model.flat_grads)  # ONE collective per step: the 4.97 MB bucket of the 10 trainable tensors
         model.sgd_step(lr, momentum=0.9, weight_decay=5e-4)
@@ -148,8 +163,15 @@ def main():
         }
         if gemm_n:
             ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
+            # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this same command
+            # (PMC counters cannot be read from inside the process); the summary is committed under profiles/.
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(pmc) and B == 256 and C == 11 and args.dtype == "bf16":
+                traffic = round(json.load(open(pmc))["traffic_bytes_per_launch"])
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.md)",
+                               "flop_per_launch": round(gemm_flop / gemm_n),
                                "kernel": "gemm_pp_kernel (persistent MFMA GEMM: all 96 vision-tower GEMM launches per step, 93 % of the step's FLOPs)",
                                "launches_per_step": gemm_n // args.steps, "avg_launch_us": round(gemm_ms * 1e3 / gemm_n, 2),
                                "gemm_share_of_step": round(gemm_ms / (elapsed * 1e3), 4),

@@ -17,9 +17,13 @@
 //    ends up with 16 CONSECUTIVE output columns of one row: the epilogue moves 32 (T) / 64 (fp32) contiguous bytes
 //    per lane and 128 / 256 contiguous bytes per row per store instruction.
 //  * Buffer descriptors bound-check the operand reads (rows >= M read as zero): no clamping, ragged M is free.
+#include <hip/hip_ext.h>
+
 #include "kernels.h"
 
 namespace mudpt {
+
+hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;  // set by the caller for ONE launch (bench.py's roofline leg)
 
 using lptr_t = __attribute__((address_space(3))) void*;
 
@@ -93,12 +97,30 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
         }
 
     auto tile_of = [&](int it) { return xcd_remap((int)blockIdx.x + it * G, ntiles); };
+    // Tile order inside an XCD's contiguous chunk: groups of GN column tiles, all row panels of a group before the next
+    // group, column fastest.  The ~32 tiles an XCD runs at once then cover ~32/GN row panels x GN weight tiles, so the GN
+    // weight tiles (GN x 393 KB at K = 768) stay in the 4 MiB L2 for the whole sweep over M instead of all N/256 tiles
+    // thrashing it (measured: FETCH_SIZE of the N = 3072 GEMMs was 6.4x the algorithmic bytes with GN = N/256).
+    const int GN = (p.flags >> 8) > 0 ? (p.flags >> 8) : ntn;
+    const int ntm = ntiles / ntn;
+    auto tile_mn = [&](int tile, int& tm, int& tn) {
+        const int tpg = ntm * GN, full = ntn / GN, ng = tile / tpg;
+        if (ng < full) {
+            const int rem = tile - ng * tpg;
+            tm = rem / GN;
+            tn = ng * GN + (rem - tm * GN);
+        } else {
+            const int wl = ntn - full * GN, rem = tile - full * tpg;
+            tm = rem / wl;
+            tn = full * GN + (rem - tm * wl);
+        }
+    };
     // The step being prefetched ("next"): k-tile n_kt of this block's n_it-th tile; all scalar, updated incrementally
     // (no division in the loop: the DMA issue sits in the read section that must stay shorter than 16 MFMAs).
     int n_kt = 0, n_it = 0, n_baseA = 0, n_baseB = 0;
     auto set_next_tile = [&](int it) {
-        const int tile = tile_of(it);
-        const int tm = tile / ntn, tn = tile - tm * ntn;
+        int tm, tn;
+        tile_mn(tile_of(it), tm, tn);
         n_baseA = tm * 256 * p.lda * 2;  // bytes (operands < 2 GiB are checked on the host)
         n_baseB = tn * 256 * p.ldb * 2;
     };
@@ -243,8 +265,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
             // Branch-free: buffer descriptors drop out-of-range lanes (ragged M, N edge), so every wave issues exactly
             // NST stores.  They are NOT waited for here: the next tile's main loop runs while they drain, and its first
             // two counted waits allow NST more operations in flight (epi_pending).
-            const int tile = tile_of(c_it++);
-            const int tm = tile / ntn, tn = tile - tm * ntn;
+            int tm, tn;
+            tile_mn(tile_of(c_it++), tm, tn);
             const int n = tn * 256 + wc * 64 + fq * 16;
             const bool n_ok = n < p.N;
             f32x4 bias4[4];
@@ -362,7 +384,14 @@ static int launch_pp(const GemmArgs& a, hipStream_t s) {
     }
     const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256, ntiles = ntm * ntn;
     const int grid = ntiles < ncu ? ntiles : ncu;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, ntn, ntiles);
+    if (g_prof_start && g_prof_stop) {
+        // measurement mode: the two events ride on the kernel's own dispatch packet (no marker packets between kernels, which
+        // cost ~7 us per pair and serialise the queue)
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g_prof_start, g_prof_stop, 0, a, ntn, ntiles);
+        g_prof_start = g_prof_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, ntn, ntiles);
+    }
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
 }

@@ -34,6 +34,7 @@ struct GemmArgs {
 int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s);
 extern int g_gemm_variant;  // tuning knob, see gemm.hip
 bool gemm_uses_pp(int epi, const GemmArgs& a);  // true if launch_gemm dispatches to gemm_pp_kernel
+extern hipEvent_t g_prof_start, g_prof_stop;     // if set, the next gemm_pp_kernel launch records them (start / end of the kernel)
 int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s);  // persistent 256x256 ping-pong kernel (gemm_pp.hip)
 
 // ------------------------------------------------------------------------------------------------

@@ -147,9 +147,10 @@ static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s) 
             m->ev.push_back(e);
         }
     }
-    HIP_TRY(hipEventRecord(m->ev[m->ev_used], s));
+    g_prof_start = m->ev[m->ev_used];
+    g_prof_stop = m->ev[m->ev_used + 1];
     const int rc = launch_gemm(m->dtype, epi, a, s);
-    HIP_TRY(hipEventRecord(m->ev[m->ev_used + 1], s));
+    g_prof_start = g_prof_stop = nullptr;
     m->ev_used += 2;
     m->ev_flop.push_back(2.0 * a.M * a.N * a.K);
     return rc;
