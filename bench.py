@@ -84,11 +84,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the MuDPT path has no CPU fallback")
+    if os.environ.get("MUDPT_BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo collectives
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")  # RCCL over xGMI
+        dist.init_process_group(os.environ.get("MUDPT_BENCH_BACKEND", "nccl"))  # "nccl" is RCCL over xGMI on ROCm
 
     from mudpt_amd.model import CustomCLIP, ModelShape
     from mudpt_amd import synth

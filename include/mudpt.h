@@ -78,6 +78,11 @@ int mudpt_bind_params(mudpt_model* m, float* params_dev, float* grads_dev);
 /* logits[B, n_cls] fp32 for images[B,3,S,S] fp32 (CLIP-normalised pixels), both device memory. */
 int mudpt_forward(mudpt_model* m, const float* images_dev, int32_t batch, float* logits_dev, void* stream);
 
+/* Same with flags.  MUDPT_FWD_REUSE_TEXT: keep the text features of the previous call (valid while the bound parameters
+ * are unchanged): the reference recomputes the text tower for every test batch (trainers/mudpt.py:170-184). */
+#define MUDPT_FWD_REUSE_TEXT 1
+int mudpt_forward_ex(mudpt_model* m, const float* images_dev, int32_t batch, float* logits_dev, int32_t flags, void* stream);
+
 /* One training step's forward + backward: loss_dev[0] = mean cross-entropy over the batch, gradients of
  * (grad_scale * loss) written to the bound gradient bucket.  logits_dev may be NULL.  grad_scale = 1/world
  * makes the sum over data-parallel ranks the gradient of the global-batch mean. */

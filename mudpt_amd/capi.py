@@ -39,6 +39,7 @@ SIGNATURES = {
                                 C.POINTER(C.c_int64 * 3)]),
     "mudpt_bind_params": (_i32, [_vp, _vp, _vp]),
     "mudpt_forward": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "mudpt_forward_ex": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp]),
     "mudpt_forward_backward": (_i32, [_vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "mudpt_sgd_step": (_i32, [_vp, _f32, _f32, _f32, _f32, _i32, _vp]),
     "mudpt_sgd_reset": (_i32, [_vp]),

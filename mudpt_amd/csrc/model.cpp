@@ -91,6 +91,7 @@ struct mudpt_model {
     std::vector<void*> allocs;
     std::vector<std::string> missing;  // weight keys not yet set
     bool prompts_set = false;
+    bool text_valid = false;  // txt_f holds the text features of the currently bound parameter values' last forward
 
     Tower vis, txt;
     // vision stem / head
@@ -517,7 +518,7 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
     return MUDPT_OK;
 }
 
-static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t s) {
+static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t s, bool reuse_text = false) {
     const mudpt_config& c = m->cfg;
     const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, C = c.n_cls;
     const int P = (c.image_size / c.patch) * (c.image_size / c.patch), Lv = m->vis.L, Lt = m->txt.L, K0 = 3 * c.patch * c.patch;
@@ -533,19 +534,24 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
     // -- text tower, trainers/mudpt.py:142-156: independent of the vision tower once the prompt learner has run, so it
     // goes to the side stream (enqueued first): its ~200 small launch-latency-bound kernels fill the CUs the big vision
     // kernels leave idle (tails of the persistent GEMMs, memory-bound LayerNorms) instead of serialising behind them.
+    // With reuse_text (inference with unchanged parameters: the reference recomputes the text tower for every test batch,
+    // trainers/mudpt.py:170-184) the text features of the previous call are kept.
     hipStream_t s2 = m->s2;
-    HIP_TRY(hipEventRecord(m->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(s2, m->ev_fork, 0));
-    HIP_TRY(hipMemcpyAsync(m->txt.a[0].x_in, m->emb_pos, (size_t)C * Lt * dt * 4, hipMemcpyDeviceToDevice, s2));
-    TRY(launch_set_rows(m->txt.a[0].x_in, C, Lt, dt, 1, n, Pm + m->off[P_CTX], m->tpos + dt, s2));
-    for (int i = 0; i < m->txt.layers; ++i) {
-        TRY(block_fwd(m, m->txt, i, C, (i >= 1 && i - 1 < D1) ? m->txt_deep + (size_t)(i - 1) * n * dt : nullptr, s2));
+    if (!reuse_text) {
+        HIP_TRY(hipEventRecord(m->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(s2, m->ev_fork, 0));
+        HIP_TRY(hipMemcpyAsync(m->txt.a[0].x_in, m->emb_pos, (size_t)C * Lt * dt * 4, hipMemcpyDeviceToDevice, s2));
+        TRY(launch_set_rows(m->txt.a[0].x_in, C, Lt, dt, 1, n, Pm + m->off[P_CTX], m->tpos + dt, s2));
+        for (int i = 0; i < m->txt.layers; ++i) {
+            TRY(block_fwd(m, m->txt, i, C, (i >= 1 && i - 1 < D1) ? m->txt_deep + (size_t)(i - 1) * n * dt : nullptr, s2));
+        }
+        LnFwdArgs lf; lf.x = m->txt.x_last; lf.ldx = dt; lf.row_index = m->eot_rows; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
+        lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = C; lf.d = dt;
+        TRY(launch_ln_fwd(m->dtype, lf, s2));
+        TRY(launch_sgemm(false, false, C, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f, e, nullptr, s2));
+        HIP_TRY(hipEventRecord(m->ev_join, s2));
+        m->text_valid = true;
     }
-    LnFwdArgs lf; lf.x = m->txt.x_last; lf.ldx = dt; lf.row_index = m->eot_rows; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
-    lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = C; lf.d = dt;
-    TRY(launch_ln_fwd(m->dtype, lf, s2));
-    TRY(launch_sgemm(false, false, C, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f, e, nullptr, s2));
-    HIP_TRY(hipEventRecord(m->ev_join, s2));
     // -- vision tower, clip/model.py:526-553
     TRY(launch_patchify(m->dtype, images, m->patches, B, c.image_size, c.patch, s));
     GemmArgs pe; pe.A = m->patches; pe.lda = K0; pe.B = m->conv_w; pe.ldb = K0; pe.M = B * P; pe.N = dv; pe.K = K0; pe.out0 = m->xpre; pe.ldo0 = dv;
@@ -564,7 +570,7 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
     TRY(launch_ln_fwd(m->dtype, lq, s));
     TRY(launch_sgemm(false, false, B, e, dv, 1.f, m->f_ln, dv, m->vproj, e, 0.f, m->img_f, e, nullptr, s));
     // -- cosine logits, trainers/mudpt.py:178-182 (needs both towers)
-    HIP_TRY(hipStreamWaitEvent(s, m->ev_join, 0));
+    if (!reuse_text) HIP_TRY(hipStreamWaitEvent(s, m->ev_join, 0));
     HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.scale = m->scale; h.logits = m->logits; h.img_n = m->img_n; h.txt_n = m->txt_n;
     h.img_inv = m->img_inv; h.txt_inv = m->txt_inv; h.B = B; h.C = C; h.e = e;
     TRY(launch_head_fwd(h, s));
@@ -572,10 +578,16 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
 }
 
 extern "C" int mudpt_forward(mudpt_model* m, const float* images, int32_t B, float* logits, void* stream) {
+    return mudpt_forward_ex(m, images, B, logits, 0, stream);
+}
+
+extern "C" int mudpt_forward_ex(mudpt_model* m, const float* images, int32_t B, float* logits, int32_t flags, void* stream) {
     TRY(ready(m, B, false));
     ARG_CHECK(images && logits, "forward: null argument");
     hipStream_t s = (hipStream_t)stream;
-    TRY(forward_impl(m, images, B, s));
+    const bool reuse = (flags & MUDPT_FWD_REUSE_TEXT) != 0;
+    if (reuse && !m->text_valid) { set_error("forward: MUDPT_FWD_REUSE_TEXT before any text-tower pass"); return MUDPT_ERR_STATE; }
+    TRY(forward_impl(m, images, B, s, reuse));
     HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * m->cfg.n_cls * 4, hipMemcpyDeviceToDevice, s));
     return MUDPT_OK;
 }

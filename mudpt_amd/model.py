@@ -113,6 +113,7 @@ class CustomCLIP(nn.Module):
             self.param_names.append(key)
         self._init_trainables(emb_w, ctx_token_ids, seed)
         self._loss = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._text_version = None  # flat_params._version the library's cached text features belong to
 
     # -- initialisation of the trainables, trainers/mudpt.py:57-81 and clip/model.py:512-519 ---------------------
     def _init_trainables(self, emb_w, ctx_token_ids, seed):
@@ -146,7 +147,12 @@ class CustomCLIP(nn.Module):
         image = image.to(self.device, torch.float32).contiguous()
         B = image.shape[0]
         logits = torch.empty(B, self.n_cls, dtype=torch.float32, device=self.device)
-        capi.check(self.lib.mudpt_forward(self._h, capi.ptr(image), B, capi.ptr(logits), self._stream()), "forward")
+        # eval mode: the text features only depend on the parameters; recompute them only when the flat bucket's version
+        # counter moved (the reference re-runs the text tower for every test batch)
+        version = self.flat_params._version
+        reuse = (not self.training) and self._text_version == version
+        capi.check(self.lib.mudpt_forward_ex(self._h, capi.ptr(image), B, capi.ptr(logits), 1 if reuse else 0, self._stream()), "forward")
+        self._text_version = version
         return logits
 
     # -- trainers/mudpt.py:249-251 minus the optimizer step: loss (device scalar) + .grad of the 10 tensors ---------------
@@ -158,10 +164,12 @@ class CustomCLIP(nn.Module):
         logits = torch.empty(B, self.n_cls, dtype=torch.float32, device=self.device) if return_logits else None
         capi.check(self.lib.mudpt_forward_backward(self._h, capi.ptr(image), capi.ptr(label), B, grad_scale,
                                                    capi.ptr(self._loss), capi.ptr(logits), self._stream()), "forward_backward")
+        self._text_version = self.flat_params._version  # the step's forward left this version's text features in the library
         return (self._loss[0], logits) if return_logits else self._loss[0]
 
     def sgd_step(self, lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, dampening: float = 0.0, nesterov: bool = False):
         capi.check(self.lib.mudpt_sgd_step(self._h, lr, momentum, weight_decay, dampening, int(nesterov), self._stream()), "sgd_step")
+        self._text_version = None  # the library wrote the parameters behind torch's version counter
 
     def profile(self, enable: bool):
         capi.check(self.lib.mudpt_profile_enable(self._h, int(enable)), "profile_enable")

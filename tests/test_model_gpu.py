@@ -148,3 +148,26 @@ def test_not_ready_fails_loudly():
     lib.mudpt_destroy(h)
     bad = capi.Config(32, 16, 192, 3, 3, 128, 3, 2, 77, 128, 2, 0, 11, 2, 1)  # depth 0: trainers/mudpt.py:52 assert
     assert lib.mudpt_create(C.byref(bad), C.byref(h)) == 1 and b"PROMPT_DEPTH" in lib.mudpt_last_error()
+
+
+def test_eval_reuses_text_features_until_parameters_change():
+    """model_inference: the text tower runs once per parameter version in eval mode, same logits."""
+    case = GoldenCase("mudpt_tiny")
+    m = build(case, "fp16")
+    m.eval()
+    a = m(case.images).clone()
+    assert m._text_version == m.flat_params._version
+    b = m(case.images).clone()            # reuse path
+    assert torch.equal(a, b)
+    with torch.no_grad():
+        m.mudpt_prompt_learner.ctx.add_(0.05)   # in-place update bumps the bucket's version -> text tower reruns
+    c = m(case.images).clone()
+    assert not torch.equal(a, c)
+    params = {k: v.detach().cpu().clone() for k, v in m.named_parameters()}
+    with torch.no_grad():
+        ref = O.forward(case.cfg, case.frozen, params, case.class_embedding, case.eot, case.images)
+    assert (c.cpu() - ref).abs().max().item() < 2e-3
+    m.train()
+    d = m(case.images)                      # training mode never reuses
+    assert torch.equal(c, d)
+    m.close()
