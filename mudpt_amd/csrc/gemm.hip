@@ -230,6 +230,7 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_PATCH) ARG_CHECK(a.pos && a.patches > 0 && a.seq_len > a.patches && a.M % a.patches == 0, "gemm: bad patch epilogue args");
     GemmArgs b = a;
     if (g_gemm_variant & 0x100) b.flags |= 1;
+    if (g_gemm_variant & 0x200) b.flags |= 2;  // gemm_pp: no half tiles in the last wave
     b.flags |= ((g_gemm_variant >> 12) & 0xff) << 8;  // bits 12..19 of the knob: column-tile group width GN of gemm_pp (0 = default)
     // default: the persistent ping-pong kernel for the big GEMMs whose epilogue needs no operand load besides bias / u
     if (gemm_uses_pp(epi, a)) return launch_gemm_pp(dtype, epi, b, s);

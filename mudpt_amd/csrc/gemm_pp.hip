@@ -39,7 +39,7 @@ __device__ inline void vmcnt() {
 }
 
 template <typename T, int EPI>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int ntiles) {
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int ntiles, int rem_half) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
     constexpr int STAGE = 65536, BOFF = 32768;
@@ -52,23 +52,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
 
     const int nkt = p.K >> 6;
     const int G = gridDim.x;
-    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
-    const int total = my_tiles * nkt;
+    // Work items of this block: my_full whole 256 x 256 tiles (b, b + G, ...), then -- when the host split the last, partial
+    // wave of tiles (rem_half of them, 2 rem_half <= G) -- one HALF tile of 128 rows x 256 columns: blocks b and b + rem_half
+    // take the upper / lower half of remainder tile b, so the tail costs half a tile time instead of a whole one
+    // (603 tiles on 256 CUs: 2.5 instead of 3 tile times).
+    const int my_full = rem_half ? ntiles / G : (ntiles - (int)blockIdx.x + G - 1) / G;
+    const bool has_half = rem_half && (int)blockIdx.x < 2 * rem_half;
+    const int total = (my_full + (has_half ? 1 : 0)) * nkt;
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((size_t)p.M * p.lda * 2 < 0xffffffffull ? (size_t)p.M * p.lda * 2 : 0xffffffffull), 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((size_t)p.N * p.ldb * 2 < 0xffffffffull ? (size_t)p.N * p.ldb * 2 : 0xffffffffull), 0x00020000);
 
     // epilogue operands through bounds-checked descriptors as well (out-of-range lanes get offset OOB: dropped / read 0)
+    static_assert(EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_GELU_BWD || EPI == EPI_STORE_F32, "epilogue not built for gemm_pp");
     constexpr int OOB = (int)0x80000000;
-    constexpr bool OUT_F32 = (EPI == EPI_RESIDUAL || EPI == EPI_PATCH || EPI == EPI_STORE_F32);
+    constexpr bool OUT_F32 = (EPI == EPI_STORE_F32);
+    // B fragment rows: permuted (a lane ends up with 16 consecutive columns = 32 bytes of T) for the T outputs, natural
+    // (4 consecutive columns per sub-tile = 16 bytes of fp32) for the fp32 output; see the epilogue.
+    constexpr bool NAT = OUT_F32;
     constexpr int NST = (EPI == EPI_STORE || EPI == EPI_GELU_BWD) ? 16 : 32;  // stores per wave per tile, exact
-    const int out_rows = EPI == EPI_PATCH ? (p.M / p.patches) * p.seq_len : p.M;
-    const auto rsOut0 = __builtin_amdgcn_make_buffer_rsrc(p.out0, 0, out_rows * p.ldo0 * (OUT_F32 ? 4 : 2), 0x00020000);
+    const auto rsOut0 = __builtin_amdgcn_make_buffer_rsrc(p.out0, 0, p.M * p.ldo0 * (OUT_F32 ? 4 : 2), 0x00020000);
     const auto rsOut1 = __builtin_amdgcn_make_buffer_rsrc(p.out1, 0, EPI == EPI_GELU ? p.M * p.ldo1 * 2 : 0, 0x00020000);
-    const auto rsAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0,
-                                                         EPI == EPI_RESIDUAL ? p.M * p.ldaux * 4 : (EPI == EPI_GELU_BWD ? p.M * p.ldaux * 2 : 0), 0x00020000);
+    const auto rsAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0, EPI == EPI_GELU_BWD ? p.M * p.ldaux * 2 : 0, 0x00020000);
     const auto rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
-    const auto rsPos = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pos), 0, EPI == EPI_PATCH ? (1 + p.patches) * p.N * 4 : 0, 0x00020000);
     bool epi_pending = false;  // the previous step ended with an epilogue: NST stores sit in the VMEM queue
 
     // ---- DMA bookkeeping: 4 units x 2 row-groups (8 rows, 1 KiB in LDS) per wave --------------------------------
@@ -80,8 +86,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
         const int k = 2 * w + q;
         grp[0][q] = k < 8 ? k : k + 8;
         grp[3][q] = k < 8 ? k + 8 : k + 16;
-        grp[1][q] = 2 * k;
-        grp[2][q] = 2 * k + 1;
+        // permuted B: sub-tiles 0, 1 read the even 8-row groups; natural B: the first four groups of every 64 rows
+        grp[1][q] = NAT ? (k >> 2) * 8 + (k & 3) : 2 * k;
+        grp[2][q] = NAT ? (k >> 2) * 8 + (k & 3) + 4 : 2 * k + 1;
     }
     const int srow = lane >> 3, sslot = lane & 7;
     // lane part of the source offset (elements): row * ld + chunk * 8, chunk = slot ^ swizzle(row)
@@ -92,11 +99,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
         for (int q = 0; q < 2; ++q) {
             const bool isA = (u == 0 || u == 3);
             const int row = grp[u][q] * 8 + srow;
-            const int f = isA ? (row & 7) : ((row & 3) | (((row >> 4) & 1) << 2));
+            const int f = (isA || NAT) ? (row & 7) : ((row & 3) | (((row >> 4) & 1) << 2));
             lane_off[u][q] = (row * (isA ? p.lda : p.ldb) + ((sslot ^ f) << 3)) * 2;  // bytes
         }
 
-    auto tile_of = [&](int it) { return xcd_remap((int)blockIdx.x + it * G, ntiles); };
     // Tile order inside an XCD's contiguous chunk: groups of GN column tiles, all row panels of a group before the next
     // group, column fastest.  The ~32 tiles an XCD runs at once then cover ~32/GN row panels x GN weight tiles, so the GN
     // weight tiles (GN x 393 KB at K = 768) stay in the 4 MiB L2 for the whole sweep over M instead of all N/256 tiles
@@ -115,19 +121,33 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
             tn = full * GN + (rem - tm * wl);
         }
     };
-    // The step being prefetched ("next"): k-tile n_kt of this block's n_it-th tile; all scalar, updated incrementally
+    // tile (and half: 0 upper / 1 lower 128 rows) of this block's it-th work item
+    auto item_tile = [&](int it, int& tm, int& tn, int& h) {
+        if (it < my_full) {
+            tile_mn(xcd_remap((int)blockIdx.x + it * G, ntiles), tm, tn);
+            h = 0;
+        } else {
+            h = (int)blockIdx.x >= rem_half ? 1 : 0;
+            tile_mn(xcd_remap(my_full * G + (int)blockIdx.x - h * rem_half, ntiles), tm, tn);
+        }
+    };
+    // The step being prefetched ("next"): k-tile n_kt of this block's n_it-th item; all scalar, updated incrementally
     // (no division in the loop: the DMA issue sits in the read section that must stay shorter than 16 MFMAs).
     int n_kt = 0, n_it = 0, n_baseA = 0, n_baseB = 0;
-    auto set_next_tile = [&](int it) {
-        int tm, tn;
-        tile_mn(tile_of(it), tm, tn);
-        n_baseA = tm * 256 * p.lda * 2;  // bytes (operands < 2 GiB are checked on the host)
+    bool n_half = false;  // the item being prefetched is the half tile: its 128 A rows are unit 0 alone, unit 3 is not issued
+    auto set_next_item = [&](int it) {
+        int tm, tn, h;
+        item_tile(it, tm, tn, h);
+        n_half = it >= my_full;
+        // bytes (operands < 4 GiB are checked on the host).  Unit 0's second half (waves 4-7) lands in LDS rows 128-191 and
+        // normally comes from tile rows 128-191; in a half tile it is rows 64-127: 64 rows less.
+        n_baseA = (tm * 256 + (n_half ? h * 128 - (w >= 4 ? 64 : 0) : 0)) * p.lda * 2;
         n_baseB = tn * 256 * p.ldb * 2;
     };
     auto advance_next = [&]() {
         if (++n_kt == nkt) {
             n_kt = 0;
-            if (++n_it < my_tiles) set_next_tile(n_it);
+            if ((++n_it) * nkt < total) set_next_item(n_it);
         }
     };
     // issue unit u of the next step into LDS stage `stage`
@@ -144,7 +164,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     const int sw = frow & 7;
     const int c0 = (fq ^ sw) << 4;           // k-step 0 chunk byte offset; k-step 1 is c0 ^ 64
     const int a_base = (wr * 128 + frow) * 128;
-    const int b_base = BOFF + (wc * 64 + (frow >> 2) * 16 + (frow & 3)) * 128;
+    const int b_base = BOFF + (NAT ? wc * 64 + frow : wc * 64 + (frow >> 2) * 16 + (frow & 3)) * 128;
+    constexpr int BJ = NAT ? 2048 : 512;  // byte step between the B fragments of consecutive sub-tiles
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -154,8 +175,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
 
     // ---- prologue: step 0 completely, then offset the second wave group by one barrier ----------------------------
     if (total > 0) {
-        set_next_tile(0);
-        issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+        set_next_item(0);
+        issue(0, 0); issue(1, 0); issue(2, 0);
+        if (!n_half) issue(3, 0);
         advance_next();
     }
     VMCNT(0);
@@ -165,165 +187,65 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     vec8 af[4][2], bf[4][2];  // A fragments of the current quadrant pair, B fragments of all 4 sub-tiles, 2 k-steps each
     int kt = 0, c_it = 0;      // the step being computed: k-tile kt of this block's c_it-th tile
 
-    for (int s = 0; s < total; ++s) {
-        const int cur = s & 1;
-        const char* st = smem + cur * STAGE;
-        const bool nxt = s + 1 < total;
-        // ================= phase 0: quadrant (rows 0-63, sub-tiles 0-1) =================
+    // 16 MFMAs of one accumulator quadrant: rows 16 (i0 + i), sub-tiles j0, j0 + 1
+    auto mfma_quadrant = [&](int i0, int j0) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i0 + i][j0 + j] = T::mfma16(bf[j0 + j][ks], af[i][ks], acc[i0 + i][j0 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_a = [&](const char* st, int i0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            af[i][0] = *(const vec8*)(st + a_base + i * 2048 + c0);
-            af[i][1] = *(const vec8*)(st + a_base + i * 2048 + (c0 ^ 64));
+            af[i][0] = *(const vec8*)(st + a_base + (i0 + i) * 2048 + c0);
+            af[i][1] = *(const vec8*)(st + a_base + (i0 + i) * 2048 + (c0 ^ 64));
         }
+    };
+    auto read_b = [&](const char* st, int j0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            bf[j][0] = *(const vec8*)(st + b_base + j * 512 + c0);
-            bf[j][1] = *(const vec8*)(st + b_base + j * 512 + (c0 ^ 64));
+        for (int j = j0; j < j0 + 2; ++j) {
+            bf[j][0] = *(const vec8*)(st + b_base + j * BJ + c0);
+            bf[j][1] = *(const vec8*)(st + b_base + j * BJ + (c0 ^ 64));
         }
-        // retire unit 2 of this step (read in phase 1): younger operations = unit 3 [2] (+ the last epilogue's stores) (+ unit 0' [2])
-        if (nxt) {
-            issue(0, cur ^ 1);
-            if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
-        } else {
-            if (epi_pending) vmcnt<NST + 2>(); else vmcnt<2>();
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma16(bf[j][ks], af[i][ks], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ================= phase 1: quadrant (rows 0-63, sub-tiles 2-3) =================
-#pragma unroll
-        for (int j = 2; j < 4; ++j) {
-            bf[j][0] = *(const vec8*)(st + b_base + j * 512 + c0);
-            bf[j][1] = *(const vec8*)(st + b_base + j * 512 + (c0 ^ 64));
-        }
-        // retire unit 3 of this step (read in phase 2): younger = (stores) + unit 0' [2] + unit 1' [2]
-        if (nxt) {
-            issue(1, cur ^ 1);
-            if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
-        } else {
-            if (epi_pending) vmcnt<NST>(); else vmcnt<0>();
-        }
-        epi_pending = false;  // phase 3's vmcnt(4) (units 0', 1' are younger than the stores) covers the stores themselves
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 2; j < 4; ++j) acc[i][j] = T::mfma16(bf[j][ks], af[i][ks], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ================= phase 2: quadrant (rows 64-127, sub-tiles 2-3) =================
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i][0] = *(const vec8*)(st + a_base + (4 + i) * 2048 + c0);
-            af[i][1] = *(const vec8*)(st + a_base + (4 + i) * 2048 + (c0 ^ 64));
-        }
-        if (nxt) issue(2, cur ^ 1);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 2; j < 4; ++j) acc[4 + i][j] = T::mfma16(bf[j][ks], af[i][ks], acc[4 + i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ================= phase 3: quadrant (rows 64-127, sub-tiles 0-1) =================
-        if (nxt) { issue(3, cur ^ 1); advance_next(); VMCNT(4); }    // retires units 0, 1 of the next step (read in its phase 0)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][j] = T::mfma16(bf[j][ks], af[i][ks], acc[4 + i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+    };
 
-        if (++kt == nkt) {
-            kt = 0;
+    auto epilogue = [&]() {
             // ---- epilogue of this output tile: lane owns out[m][n0 .. n0 + 15], m = sub-tile row (lane & 15) ----
             // Branch-free: buffer descriptors drop out-of-range lanes (ragged M, N edge), so every wave issues exactly
             // NST stores.  They are NOT waited for here: the next tile's main loop runs while they drain, and its first
             // two counted waits allow NST more operations in flight (epi_pending).
-            int tm, tn;
-            tile_mn(tile_of(c_it++), tm, tn);
-            const int n = tn * 256 + wc * 64 + fq * 16;
-            const bool n_ok = n < p.N;
-            f32x4 bias4[4];
+            int tm, tn, h;
+            const bool c_half = c_it >= my_full;  // a half tile: rows h * 128 + wr * 64 + 16 i, i < 4
+            item_tile(c_it++, tm, tn, h);
+            const int ni = c_half ? 4 : 8;
+            // T outputs: lane owns columns n .. n + 15 of row m (two 16-byte pieces, 16 bytes apart);
+            // fp32 output: lane owns columns n + 16 j .. + 3 of row m for j = 0..3 (pieces of a pair (2J, 2J+1) are 64 bytes apart)
+            const int n = tn * 256 + wc * 64 + (NAT ? fq * 4 : fq * 16);
+            f32x4 bias4[4];  // the bias descriptor ends at N: columns beyond it read 0
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                bias4[j] = p.bias ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsBias, n_ok ? (n + 4 * j) * 4 : OOB, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const int m_base = tm * 256 + wr * 128 + frow;
-            // byte offset of this lane's 16-column run in row (m_base + 16 i) of a [rows][ld] array, OOB when masked
-            auto row_off = [&](int i, int ld, int esz) {
-                const int m = m_base + i * 16;
-                int orow = m;
-                if constexpr (EPI == EPI_PATCH) {
-                    const int b = m / p.patches;
-                    orow = b * p.seq_len + 1 + (m - b * p.patches);
-                }
-                return (n_ok && m < p.M) ? (orow * ld + n) * esz : OOB;
-            };
+                bias4[j] = p.bias ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsBias, (n + (NAT ? 16 : 4) * j) * 4, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int m_base = tm * 256 + (c_half ? h * 128 + wr * 64 : wr * 128) + frow;
+            // byte offset of column `col` in row (m_base + 16 i) of a [rows][ld] array.  Rows >= M lie beyond the descriptor's
+            // range (dropped / read as 0); a column beyond N moves the lane out of range.
+            auto row_off = [&](int i, int ld, int esz, int col) { return (col < p.N ? (m_base * ld + col) * esz : OOB) + i * (16 * ld * esz); };
             // ---- pass 1: everything that needs a LOAD is folded into the accumulators, all loads before any store
             // (vmcnt retires in issue order: a load waited for behind a store also waits for that store's completion)
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] += bias4[j];
-            if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_PATCH) {
-#pragma unroll
-                for (int h = 0; h < 3; ++h) {  // batches of 3 + 3 + 2 rows x 64 bytes: <= 48 VGPRs of loads in flight
-                    constexpr int RB = 3;
-                    f32x4 r[RB][4];
-#pragma unroll
-                    for (int ii = 0; ii < RB; ++ii) {
-                        const int i = RB * h + ii;
-                        if (i < 8) {
-                            int off;
-                            if constexpr (EPI == EPI_RESIDUAL) {
-                                off = row_off(i, p.ldaux, 4);
-                            } else {
-                                const int m = m_base + i * 16;
-                                off = (n_ok && m < p.M) ? ((1 + m % p.patches) * p.N + n) * 4 : OOB;
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                r[ii][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(EPI == EPI_RESIDUAL ? rsAux : rsPos, off, 16 * j, 0));
-                        }
-                    }
-#pragma unroll
-                    for (int ii = 0; ii < RB; ++ii)
-                        if (RB * h + ii < 8) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[RB * h + ii][j] += r[ii][j];
-                        }
-                    __builtin_amdgcn_sched_barrier(0);  // keep the next batch's loads behind this batch's adds (registers)
-                }
-            } else if constexpr (EPI == EPI_GELU_BWD) {
+            if constexpr (EPI == EPI_GELU_BWD) {
                 vec8 u[8][2];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int off = row_off(i, p.ldaux, 2);
+                    const int off = i < ni ? row_off(i, p.ldaux, 2, n) : OOB;
                     u[i][0] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off, 0, 0));
                     u[i][1] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off, 16, 0));
                 }
@@ -335,18 +257,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                         for (int c = 0; c < 4; ++c) acc[i][j][c] *= quick_gelu_grad((float)u[i][j >> 1][4 * (j & 1) + c]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- pass 2: stores only (exactly NST per wave)
+            // ---- pass 2: stores only (exactly NST per wave).  One CU drains ~16 bytes per clock (tools/probes/store_pattern.hip:
+            // 31-33 GB/s per CU whatever the lane -> address map), so a 128 KiB tile costs ~4 us that nothing overlaps.
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+                if (i < ni) {  // uniform: a half tile (always the block's last item) stores 4 of the 8 sub-tile rows
                 if constexpr (OUT_F32) {
-                    const int off = row_off(i, p.ldo0, 4);
+                    // natural layout: the 4 lanes of a row write 64 contiguous bytes per instruction (permuted: 16-byte pieces
+                    // 64 bytes apart, measured 1.55x slower)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsOut0, off, 16 * j, 0);
+                    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsOut0, row_off(i, p.ldo0, 4, n + 16 * j), 0, 0);
                 } else {
                     vec8 o0, o1;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { o0[c] = (elem)acc[i][0][c]; o0[4 + c] = (elem)acc[i][1][c]; o1[c] = (elem)acc[i][2][c]; o1[4 + c] = (elem)acc[i][3][c]; }
-                    const int off = row_off(i, p.ldo0, 2);
+                    const int off = row_off(i, p.ldo0, 2, n);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut0, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut0, off, 16, 0);
                     if constexpr (EPI == EPI_GELU) {
@@ -355,16 +280,96 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                             o0[c] = (elem)quick_gelu(acc[i][0][c]); o0[4 + c] = (elem)quick_gelu(acc[i][1][c]);
                             o1[c] = (elem)quick_gelu(acc[i][2][c]); o1[4 + c] = (elem)quick_gelu(acc[i][3][c]);
                         }
-                        const int off1 = row_off(i, p.ldo1, 2);
+                        const int off1 = row_off(i, p.ldo1, 2, n);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut1, off1, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut1, off1, 16, 0);
                     }
+                }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             epi_pending = true;
+    };
+
+    const int full_steps = my_full * nkt;
+    for (int s = 0; s < full_steps; ++s) {
+        const int cur = s & 1;
+        const char* st = smem + cur * STAGE;
+        const bool nxt = s + 1 < total;
+        {
+            // ================= phase 0: quadrant (rows 0-63, sub-tiles 0-1) =================
+            read_a(st, 0);
+            read_b(st, 0);
+            // retire unit 2 of this step (read in phase 1): younger operations = unit 3 [2] (+ the last epilogue's stores) (+ unit 0' [2])
+            if (nxt) {
+                issue(0, cur ^ 1);
+                if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
+            } else {
+                if (epi_pending) vmcnt<NST + 2>(); else vmcnt<2>();
+            }
+            __builtin_amdgcn_s_barrier();
+            mfma_quadrant(0, 0);
+            __builtin_amdgcn_s_barrier();
+            // ================= phase 1: quadrant (rows 0-63, sub-tiles 2-3) =================
+            read_b(st, 2);
+            // retire unit 3 of this step (read in phase 2): younger = (stores) + unit 0' [2] + unit 1' [2]
+            if (nxt) {
+                issue(1, cur ^ 1);
+                if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
+            } else {
+                if (epi_pending) vmcnt<NST>(); else vmcnt<0>();
+            }
+            epi_pending = false;  // phase 3's wait (units 0', 1' are younger than the stores) covers the stores themselves
+            __builtin_amdgcn_s_barrier();
+            mfma_quadrant(0, 2);
+            __builtin_amdgcn_s_barrier();
+            // ================= phase 2: quadrant (rows 64-127, sub-tiles 2-3) =================
+            read_a(st, 4);
+            if (nxt) issue(2, cur ^ 1);
+            __builtin_amdgcn_s_barrier();
+            mfma_quadrant(4, 2);
+            __builtin_amdgcn_s_barrier();
+            // ================= phase 3: quadrant (rows 64-127, sub-tiles 0-1) =================
+            // retires units 0, 1 of the next step (read in its phase 0); a half tile has no unit 3
+            if (nxt) {
+                if (!n_half) { issue(3, cur ^ 1); advance_next(); VMCNT(4); } else { advance_next(); VMCNT(2); }
+            }
+            __builtin_amdgcn_s_barrier();
+            mfma_quadrant(4, 0);
+            __builtin_amdgcn_s_barrier();
         }
+        if (++kt == nkt) { kt = 0; epilogue(); }
+    }
+    for (int s = full_steps; s < total; ++s) {
+        const int cur = s & 1;
+        const char* st = smem + cur * STAGE;
+        const bool nxt = s + 1 < total;
+        {
+            // ---- a K-step of the half tile: 64 rows per wave, two phases, units 0 (A), 1, 2 (B) only ----
+            // ================= phase 0: (rows 0-63, sub-tiles 0-1) =================
+            read_a(st, 0);
+            read_b(st, 0);
+            // retire unit 2 of this step (read in phase 1): younger = (the last full tile's stores) + units 0', 1' [4]
+            if (nxt) {
+                issue(0, cur ^ 1);
+                issue(1, cur ^ 1);
+                if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
+            } else {
+                if (epi_pending) vmcnt<NST>(); else vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            mfma_quadrant(0, 0);
+            __builtin_amdgcn_s_barrier();
+            // ================= phase 1: (rows 0-63, sub-tiles 2-3) =================
+            read_b(st, 2);
+            if (nxt) { issue(2, cur ^ 1); advance_next(); VMCNT(2); }  // retires units 0', 1' (and any stores before them)
+            epi_pending = false;
+            __builtin_amdgcn_s_barrier();
+            mfma_quadrant(0, 2);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (++kt == nkt) { kt = 0; epilogue(); }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the second group's extra barrier
 }
@@ -383,14 +388,18 @@ static int launch_pp(const GemmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256, ntiles = ntm * ntn;
-    const int grid = ntiles < ncu ? ntiles : ncu;
+    // grid = CUs; a last partial wave of R tiles with 2 R <= grid is run as 2 R half tiles (see the kernel); fewer tiles
+    // than half the CUs: every tile is split
+    int grid = ntiles < ncu ? (2 * ntiles <= ncu ? 2 * ntiles : ntiles) : ncu;
+    if (a.flags & 2) grid = ntiles < ncu ? ntiles : ncu;  // tuning knob: no half tiles
+    const int rem = ntiles % grid, rem_half = (rem > 0 && 2 * rem <= grid && !(a.flags & 2)) ? rem : 0;
     if (g_prof_start && g_prof_stop) {
         // measurement mode: the two events ride on the kernel's own dispatch packet (no marker packets between kernels, which
         // cost ~7 us per pair and serialise the queue)
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g_prof_start, g_prof_stop, 0, a, ntn, ntiles);
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g_prof_start, g_prof_stop, 0, a, ntn, ntiles, rem_half);
         g_prof_start = g_prof_stop = nullptr;
     } else {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, ntn, ntiles);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, ntn, ntiles, rem_half);
     }
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
@@ -412,6 +421,8 @@ static int launch_pp_t(int epi, const GemmArgs& a, hipStream_t s) {
 int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     ARG_CHECK((size_t)a.M * a.lda * 2 < 0xffffffffull && (size_t)a.N * a.ldb * 2 < 0xffffffffull, "gemm_pp: operand larger than 4 GiB");
     ARG_CHECK(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldo0 % 8 == 0, "gemm_pp: strides must be multiples of 8");
+    // epilogue offsets are 32-bit and rely on the descriptors' range check for rows >= M
+    ARG_CHECK((size_t)a.M * a.ldo0 * 4 < 0x7fffffffull && (size_t)a.M * (size_t)(a.ldo1 > a.ldaux ? a.ldo1 : a.ldaux) * 2 < 0x7fffffffull, "gemm_pp: output larger than 2 GiB");
     if (dtype == DT_BF16) return launch_pp_t<BF16>(epi, a, s);
     if (dtype == DT_F16) return launch_pp_t<F16>(epi, a, s);
     set_error("gemm: unknown dtype %d", dtype);

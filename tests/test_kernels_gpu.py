@@ -52,8 +52,30 @@ def test_gemm_exact_integers(lib, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("shape", [(804, 2304, 768), (847, 512, 2048), (77, 128, 64), (4096, 768, 3072), (33000, 768, 768)])
+def test_gemm_exact_integers_full_size(lib, dtype):
+    """BASELINE config 2's row count (M = 256 x 201): 603 tiles = two full waves + 91 tiles run as 182 half tiles.
+    Small-integer operands make every fp32 sum exact, so full and half tiles must be bit-exact."""
+    dt, tt = DT[dtype]
+    M, N, K = 51456, 768, 256
+    g = torch.Generator().manual_seed(1)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = (torch.arange(N).view(N, 1) % 7 - 3 + (torch.arange(K).view(1, K) % 4)).float()
+    ref = A @ B.t()
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    gemm(lib, dt, 5, A.cuda().to(tt), B.cuda().to(tt), out0=out)
+    assert torch.equal(out.cpu(), ref)
+    outT = torch.empty(M, N, device="cuda", dtype=tt)  # |values| <= 3 * 6 * 256 is exact in bf16? no: compare after the same rounding
+    gemm(lib, dt, 0, A.cuda().to(tt), B.cuda().to(tt), out0=outT)
+    assert torch.equal(outT.cpu(), ref.to(tt))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(804, 2304, 768), (847, 512, 2048), (77, 128, 64), (4096, 768, 3072), (33000, 768, 768),
+                                   (22100, 768, 768), (51400, 768, 192)])
 def test_gemm_epilogues(lib, dtype, shape):
+    """All fused epilogues against a float64 product.  The last two shapes leave a partial last wave of 256 x 256 tiles on 256
+    CUs (261 = 256 + 5 and 603 = 2 * 256 + 91 tiles), which the persistent kernel runs as half tiles; both have a ragged
+    last row panel (22100: the lower half tile is entirely out of range)."""
     dt, tt = DT[dtype]
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N + K)

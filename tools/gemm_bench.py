@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--epi", type=int, default=-1, help="only the shapes with this epilogue")
     a = ap.parse_args()
     lib = capi.load()
     dt, tt = (0, torch.bfloat16) if a.dtype == "bf16" else (1, torch.float16)
@@ -37,7 +38,7 @@ def main():
     P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     total = {v: 0.0 for v in variants}
     for name, M, N, K, epi in SHAPES:
-        if a.only and a.only not in name:
+        if (a.only and a.only not in name) or (a.epi >= 0 and epi != a.epi):
             continue
         A = torch.randn(M, K, device="cuda").to(tt)
         B = (torch.randn(N, K, device="cuda") * K ** -0.5).to(tt)
