@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--gemm-variant", type=int, default=0, help="tuning knob passed to mudpt_debug_set (A/B runs on one box)")
+    ap.add_argument("--fp32-streams", action="store_true", help="keep the update / gradient streams in fp32 (A/B of the bf16 streams)")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a captured hipGraph (implies --no-profile)")
     args = ap.parse_args()
 
@@ -93,7 +95,11 @@ def main():
         dist.init_process_group(os.environ.get("MUDPT_BENCH_BACKEND", "nccl"))  # "nccl" is RCCL over xGMI on ROCm
 
     from mudpt_amd.model import CustomCLIP, ModelShape
-    from mudpt_amd import synth
+    from mudpt_amd import synth, capi
+    if args.gemm_variant:
+        capi.check(capi.load().mudpt_debug_set(b"gemm_variant", args.gemm_variant))
+    if args.fp32_streams:
+        capi.check(capi.load().mudpt_debug_set(b"lp_grad", 0))
     shape = ModelShape()  # CLIP ViT-B/16, n_ctx 4, depth 12
     B, C = args.batch, args.classes
     tok = synth.bench_tokenized_prompts() if C == 11 else synth.synthetic_tokenized_prompts(C)

@@ -52,6 +52,7 @@ struct LnFwdArgs {
     // [ov_row0, ov_row0 + ov_n) are REPLACED by ov_rows[(r % ov_L) - ov_row0] (the deep-prompt splice,
     // clip/model.py:281-297); v is written to xout[r] (the block input the backward needs) and normalised.
     const float* add = nullptr; int ldadd = 0;
+    const void* add_lp = nullptr;              // ... or the addend in T (stride ldadd) when the update stream is kept in T
     float* xout = nullptr; int ldxout = 0;
     const float* ov_rows = nullptr; int ov_row0 = 0, ov_n = 0, ov_L = 1;
 };

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs p) {
         if (pos >= 0 && pos < p.ov_n) ov = (const f32x4*)(p.ov_rows + (size_t)pos * p.d);
     }
     const f32x4* add = (p.add && !ov) ? (const f32x4*)(p.add + xr * p.ldadd) : nullptr;
+    const typename T::vec4* add_lp = (p.add_lp && !ov) ? (const typename T::vec4*)((const elem*)p.add_lp + xr * p.ldadd) : nullptr;
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
         const int i = lane + 64 * k;
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs p) {
         if (i < d4) {
             v[k] = ov ? ov[i] : x[i];
             if (add) v[k] += add[i];
+            if (add_lp) { const typename T::vec4 a = add_lp[i]; v[k] += f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]}; }
             if (p.xout) ((f32x4*)(p.xout + xr * p.ldxout))[i] = v[k];
         }
         s += v[k][0] + v[k][1] + v[k][2] + v[k][3];

@@ -467,11 +467,15 @@ static int ready(mudpt_model* m, int B, bool need_grads) {
 // spliced in (splice != null), and writes it for the backward; LN2 computes x_mid[i] = x_in[i] + upd.
 static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* splice, hipStream_t s) {
     const int M = nseq * t.L, d = t.d, dt = m->dtype, n = m->cfg.n_ctx;
+    // bf16 mode: the update stream (out_proj / c_proj results) is kept in T like the gradient stream -- half the store time
+    // of those GEMMs and 2 bytes less per element in the LayerNorm that adds it.  The last block's c_proj stays fp32 (launch_add).
+    const bool lp = m->lp_grad;
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
     LnFwdArgs l1; l1.x = a.x_in; l1.ldx = d; l1.gamma = w.ln1_g; l1.beta = w.ln1_b; l1.out = t.h; l1.ldo = d; l1.mean = a.mean1; l1.rstd = a.rstd1; l1.rows = M; l1.d = d;
     if (i > 0) {
-        l1.x = t.a[i - 1].x_mid; l1.add = t.upd; l1.ldadd = d; l1.xout = a.x_in; l1.ldxout = d;
+        l1.x = t.a[i - 1].x_mid; l1.ldadd = d; l1.xout = a.x_in; l1.ldxout = d;
+        if (lp) l1.add_lp = t.upd; else l1.add = t.upd;
         if (splice) { l1.ov_rows = splice; l1.ov_row0 = t.prompt_row0; l1.ov_n = n; l1.ov_L = t.L; }
     }
     TRY(launch_ln_fwd(dt, l1, s));
@@ -480,14 +484,14 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
     TRY(launch_attn_fwd(dt, at, s));
     GemmArgs o; o.A = a.attn; o.lda = d; o.B = w.w_out; o.ldb = d; o.M = M; o.N = d; o.K = d; o.bias = w.b_out; o.out0 = t.upd; o.ldo0 = d;
-    TRY(gemm_call(m, EPI_STORE_F32, o, s));
-    LnFwdArgs l2; l2.x = a.x_in; l2.ldx = d; l2.add = t.upd; l2.ldadd = d; l2.xout = a.x_mid; l2.ldxout = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = d;
+    TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, o, s));
+    LnFwdArgs l2; l2.x = a.x_in; l2.ldx = d; if (lp) l2.add_lp = t.upd; else l2.add = t.upd; l2.ldadd = d; l2.xout = a.x_mid; l2.ldxout = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = d;
     l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = M; l2.d = d;
     TRY(launch_ln_fwd(dt, l2, s));
     GemmArgs f; f.A = t.h; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = M; f.N = 4 * d; f.K = d; f.bias = w.b_fc; f.out0 = a.u; f.ldo0 = 4 * d; f.out1 = t.g; f.ldo1 = 4 * d;
     TRY(gemm_call(m, EPI_GELU, f, s));
     GemmArgs p; p.A = t.g; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = M; p.N = d; p.K = 4 * d; p.bias = w.b_proj; p.out0 = t.upd; p.ldo0 = d;
-    TRY(gemm_call(m, EPI_STORE_F32, p, s));
+    TRY(gemm_call(m, (lp && i + 1 < t.layers) ? EPI_STORE : EPI_STORE_F32, p, s));
     if (i + 1 == t.layers) TRY(launch_add(a.x_mid, t.upd, t.x_last, (size_t)M * d, s));  // output of the last block
     return MUDPT_OK;
 }
