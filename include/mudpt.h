@@ -100,8 +100,9 @@ int mudpt_sgd_step(mudpt_model* m, float lr, float momentum, float weight_decay,
 int mudpt_sgd_reset(mudpt_model* m);
 
 /* Test hook: copy an internal fp32 activation of the last call to HOST memory (synchronises the device).
- * name: "vis.x_in.<i>" / "txt.x_in.<i>" (input of block i, after the prompt splice), "vis.x_out" / "txt.x_out"
- * (output of the last block), "image_features", "text_features".  host_out may be NULL to query *numel. */
+ * name: "vis.x_in.<i>" / "txt.x_in.<i>" (input of block i, after the prompt splice; [seq, L, d]), "vis.x_out" / "txt.x_out"
+ * (output of the last block on the ONE row per sequence the model uses -- CLS / EOT token -- [seq, d]: the tail of the last
+ * block runs on those rows only), "image_features", "text_features".  host_out may be NULL to query *numel. */
 int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* host_out, size_t capacity, size_t* numel);
 
 /* Tuning knob for A/B measurements in one process (tools/gemm_bench.py): "gemm_variant". */

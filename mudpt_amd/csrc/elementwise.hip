@@ -7,6 +7,8 @@
 
 namespace mudpt {
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4v;
+
 // ---- patchify: images fp32 [B,3,S,S] -> patches T [B*P, 3*p*p], inner order (c, py, px) = conv1.weight.reshape(out, -1)
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, typename T::elem* __restrict__ out, int B,
@@ -53,6 +55,30 @@ __global__ __launch_bounds__(256) void set_rows_kernel(float* __restrict__ x, in
 int launch_set_rows(float* x, int B, int L, int d, int row0, int n, const float* rows, const float* add, hipStream_t s) {
     ARG_CHECK(x && rows && B > 0 && n > 0 && row0 >= 0 && row0 + n <= L && d % 4 == 0, "set_rows: bad arguments");
     hipLaunchKernelGGL(set_rows_kernel, dim3(B * n), dim3(256), 0, s, x, L, d, row0, n, rows, add);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+// ---- move_rows: dst[dmap(r)] = src[smap(r)] for whole rows of row_bytes (multiple of 16), map = rows[r] or r: the gather /
+// scatter of the one row per sequence (CLS / EOT token) that the last block's tail works on
+__global__ __launch_bounds__(256) void move_rows_kernel(const char* __restrict__ src, size_t src_stride, const int* __restrict__ src_rows,
+                                                        char* __restrict__ dst, size_t dst_stride, const int* __restrict__ dst_rows, int row_bytes) {
+    const int r = blockIdx.x;
+    const u32x4v* in = (const u32x4v*)(src + (size_t)(src_rows ? src_rows[r] : r) * src_stride);
+    u32x4v* out = (u32x4v*)(dst + (size_t)(dst_rows ? dst_rows[r] : r) * dst_stride);
+    for (int k = threadIdx.x; k < row_bytes / 16; k += blockDim.x) out[k] = in[k];
+}
+
+int launch_gather_rows(const void* src, size_t src_stride, const int* rows, void* dst, size_t dst_stride, int nrows, int row_bytes, hipStream_t s) {
+    ARG_CHECK(src && dst && rows && nrows > 0 && row_bytes > 0 && row_bytes % 16 == 0 && src_stride % 16 == 0 && dst_stride % 16 == 0, "gather_rows: bad arguments");
+    hipLaunchKernelGGL(move_rows_kernel, dim3(nrows), dim3(256), 0, s, (const char*)src, src_stride, rows, (char*)dst, dst_stride, (const int*)nullptr, row_bytes);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+int launch_scatter_rows(const void* src, size_t src_stride, const int* rows, void* dst, size_t dst_stride, int nrows, int row_bytes, hipStream_t s) {
+    ARG_CHECK(src && dst && rows && nrows > 0 && row_bytes > 0 && row_bytes % 16 == 0 && src_stride % 16 == 0 && dst_stride % 16 == 0, "scatter_rows: bad arguments");
+    hipLaunchKernelGGL(move_rows_kernel, dim3(nrows), dim3(256), 0, s, (const char*)src, src_stride, (const int*)nullptr, (char*)dst, dst_stride, rows, row_bytes);
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
 }

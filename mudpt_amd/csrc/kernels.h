@@ -95,6 +95,9 @@ int launch_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s);
 int launch_patchify(int dtype, const float* images, void* patches, int B, int image_size, int patch, hipStream_t s);
 // x[b, row0 + i, :] = rows[i, :] (+ add[i, :])  for i < n : CLS row, prompt rows, deep-prompt splice.
 int launch_set_rows(float* x, int B, int L, int d, int row0, int n, const float* rows, const float* add, hipStream_t s);
+// dst[r] = src[rows[r]] (gather) / dst[rows[r]] = src[r] (scatter): whole rows of row_bytes (multiple of 16), strides in bytes.
+int launch_gather_rows(const void* src, size_t src_stride, const int* rows, void* dst, size_t dst_stride, int nrows, int row_bytes, hipStream_t s);
+int launch_scatter_rows(const void* src, size_t src_stride, const int* rows, void* dst, size_t dst_stride, int nrows, int row_bytes, hipStream_t s);
 // out[i, :] = sum_b src[b, row0 + i, :] in fixed order (deterministic); optionally zero the source rows
 // (fp32 and its T copy) afterwards: backward of the splice.  accumulate: out += instead of =.
 // scale multiplies the sum (undoes the static loss scale of the backward pass).

@@ -71,14 +71,21 @@ struct Tower {
     bool causal = false;
     int prompt_row0 = 0;  // first prompt row inside a sequence (vision: L - n, text: 1)
     std::vector<BlockW> w;
-    std::vector<BlockAct> a;  // layers entries; x_out of the last block lives in x_last
-    float* x_last = nullptr;
+    std::vector<BlockAct> a;  // layers entries; the last block's output exists on the tail rows only (xout_sel)
     // scratch shared by all blocks
     void *h = nullptr, *g = nullptr;                    // T [M,d], T [M,4d]
     float* dx = nullptr; void* dx_lp = nullptr;         // gradient residual stream fp32 + T copy
     void *dattn = nullptr, *dqkv = nullptr;             // T
     float* delta = nullptr;
     float* upd = nullptr;  // fp32 [M, d]: out_proj / c_proj result, added to the stream by the next LayerNorm kernel
+    // Tail of the last block.  Only ONE row per sequence of the last block's output is ever used (the CLS token,
+    // clip/model.py:549, or the EOT token, trainers/mudpt.py:154), so everything after that block's attention -- out_proj,
+    // ln_2, the MLP, the residual adds and their backward -- runs on those max_seq rows only ("sel": compact [max_seq, *]).
+    // Results are identical to the reference's: the other rows of its last block output are computed and dropped.
+    const int* tail_rows = nullptr;  // [nseq] token row (b * L + position) of the used row of every sequence
+    float *xin_sel = nullptr, *xmid_sel = nullptr, *xout_sel = nullptr;  // fp32 [S, d]
+    void *attn_sel = nullptr, *h_sel = nullptr, *u_sel = nullptr, *g_sel = nullptr, *dattn_sel = nullptr;  // T
+    float* dsel = nullptr; void* dsel_lp = nullptr;  // gradient of the residual stream on the selected rows (fp32 / T)
 };
 
 }  // namespace mudpt
@@ -207,12 +214,15 @@ static int alloc_tower(mudpt_model* m, Tower& t, int d, int layers, int heads, i
         ALLOC(a.qkv, M * 3 * d * 2); ALLOC(a.attn, M * d * 2); ALLOC(a.u, M * 4 * d * 2);
         ALLOC(a.lse, (size_t)max_seq * heads * t.Lp * 4);
     }
-    ALLOC(t.x_last, M * d * 4);
     ALLOC(t.h, M * d * 2); ALLOC(t.g, M * 4 * d * 2);
     ALLOC(t.dx, M * d * 4); ALLOC(t.dx_lp, M * d * 2);
     ALLOC(t.dattn, M * d * 2); ALLOC(t.dqkv, M * 3 * d * 2);
     ALLOC(t.delta, (size_t)max_seq * heads * t.Lp * 4);
     ALLOC(t.upd, M * d * 4);
+    const size_t S = (size_t)max_seq;
+    ALLOC(t.xin_sel, S * d * 4); ALLOC(t.xmid_sel, S * d * 4); ALLOC(t.xout_sel, S * d * 4);
+    ALLOC(t.attn_sel, S * d * 2); ALLOC(t.h_sel, S * d * 2); ALLOC(t.u_sel, S * 4 * d * 2); ALLOC(t.g_sel, S * 4 * d * 2); ALLOC(t.dattn_sel, S * d * 2);
+    ALLOC(t.dsel, S * d * 4); ALLOC(t.dsel_lp, S * d * 2);
     return MUDPT_OK;
 }
 
@@ -281,6 +291,8 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
             for (int i = 0; i < n; ++i) pr[(size_t)b * n + i] = b * Lv + (Lv - n) + i;
         }
         HIP_TRY(hipMemcpy(m->cls_rows, cr.data(), cr.size() * 4, hipMemcpyHostToDevice));
+        m->vis.tail_rows = m->cls_rows;
+        m->txt.tail_rows = m->eot_rows;  // filled by mudpt_set_class_prompts
         HIP_TRY(hipMemcpy(m->vprompt_rows, pr.data(), pr.size() * 4, hipMemcpyHostToDevice));
         return MUDPT_OK;
     };
@@ -460,6 +472,25 @@ static int ready(mudpt_model* m, int B, bool need_grads) {
     return MUDPT_OK;
 }
 
+// Forward of the last block after its attention, on the one used row of every sequence (Tower::tail_rows): gathers the
+// rows, then out_proj (+ residual in the small GEMM's epilogue), ln_2, c_fc + QuickGELU, c_proj (+ residual) -> t.xout_sel.
+static int block_fwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
+    const int i = t.layers - 1, S = nseq, d = t.d, dt = m->dtype;
+    BlockW& w = t.w[i];
+    BlockAct& a = t.a[i];
+    TRY(launch_gather_rows(a.attn, (size_t)d * 2, t.tail_rows, t.attn_sel, (size_t)d * 2, S, d * 2, s));
+    TRY(launch_gather_rows(a.x_in, (size_t)d * 4, t.tail_rows, t.xin_sel, (size_t)d * 4, S, d * 4, s));
+    GemmArgs o; o.A = t.attn_sel; o.lda = d; o.B = w.w_out; o.ldb = d; o.M = S; o.N = d; o.K = d; o.bias = w.b_out; o.out0 = t.xmid_sel; o.ldo0 = d; o.aux = t.xin_sel; o.ldaux = d;
+    TRY(gemm_call(m, EPI_RESIDUAL, o, s));
+    LnFwdArgs l2; l2.x = t.xmid_sel; l2.ldx = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h_sel; l2.ldo = d; l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = S; l2.d = d;
+    TRY(launch_ln_fwd(dt, l2, s));
+    GemmArgs f; f.A = t.h_sel; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = S; f.N = 4 * d; f.K = d; f.bias = w.b_fc; f.out0 = t.u_sel; f.ldo0 = 4 * d; f.out1 = t.g_sel; f.ldo1 = 4 * d;
+    TRY(gemm_call(m, EPI_GELU, f, s));
+    GemmArgs p; p.A = t.g_sel; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = S; p.N = d; p.K = 4 * d; p.bias = w.b_proj; p.out0 = t.xout_sel; p.ldo0 = d; p.aux = t.xmid_sel; p.ldaux = d;
+    TRY(gemm_call(m, EPI_RESIDUAL, p, s));
+    return MUDPT_OK;
+}
+
 // Block i of a tower.  The residual adds are NOT in the GEMM epilogues: out_proj / c_proj write their fp32 result
 // (+ bias) to t.upd and the FOLLOWING LayerNorm kernel adds it to the stream while it reads it (the stream has to
 // pass through that kernel anyway; a GEMM epilogue that loads the residual stalls behind its own stores, since
@@ -483,6 +514,7 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
     TRY(gemm_call(m, EPI_STORE, q, s));
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
     TRY(launch_attn_fwd(dt, at, s));
+    if (i + 1 == t.layers) return block_fwd_tail(m, t, nseq, s);
     GemmArgs o; o.A = a.attn; o.lda = d; o.B = w.w_out; o.ldb = d; o.M = M; o.N = d; o.K = d; o.bias = w.b_out; o.out0 = t.upd; o.ldo0 = d;
     TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, o, s));
     LnFwdArgs l2; l2.x = a.x_in; l2.ldx = d; if (lp) l2.add_lp = t.upd; else l2.add = t.upd; l2.ldadd = d; l2.xout = a.x_mid; l2.ldxout = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = d;
@@ -491,8 +523,45 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
     GemmArgs f; f.A = t.h; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = M; f.N = 4 * d; f.K = d; f.bias = w.b_fc; f.out0 = a.u; f.ldo0 = 4 * d; f.out1 = t.g; f.ldo1 = 4 * d;
     TRY(gemm_call(m, EPI_GELU, f, s));
     GemmArgs p; p.A = t.g; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = M; p.N = d; p.K = 4 * d; p.bias = w.b_proj; p.out0 = t.upd; p.ldo0 = d;
-    TRY(gemm_call(m, (lp && i + 1 < t.layers) ? EPI_STORE : EPI_STORE_F32, p, s));
-    if (i + 1 == t.layers) TRY(launch_add(a.x_mid, t.upd, t.x_last, (size_t)M * d, s));  // output of the last block
+    TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, p, s));
+    return MUDPT_OK;
+}
+
+// Backward of the last block's tail (see Tower::tail_rows).  in: t.dsel / t.dsel_lp = gradient w.r.t. the selected rows of
+// the tower output; out: t.dx / t.dx_lp = gradient w.r.t. the last block's input, all rows.
+static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
+    const int i = t.layers - 1, M = nseq * t.L, S = nseq, d = t.d, dt = m->dtype;
+    const size_t esz = 2;
+    BlockW& w = t.w[i];
+    BlockAct& a = t.a[i];
+    GemmArgs g1; g1.A = t.dsel_lp; g1.lda = d; g1.B = w.w_proj_t; g1.ldb = d; g1.M = S; g1.N = 4 * d; g1.K = d; g1.out0 = t.g_sel; g1.ldo0 = 4 * d; g1.aux = t.u_sel; g1.ldaux = 4 * d;
+    TRY(gemm_call(m, EPI_GELU_BWD, g1, s));
+    GemmArgs g2; g2.A = t.g_sel; g2.lda = 4 * d; g2.B = w.w_fc_t; g2.ldb = 4 * d; g2.M = S; g2.N = d; g2.K = 4 * d; g2.out0 = t.h_sel; g2.ldo0 = d;
+    TRY(gemm_call(m, EPI_STORE, g2, s));
+    LnBwdArgs b2; b2.dy = t.h_sel; b2.lddy = d; b2.x = t.xmid_sel; b2.ldx = d; b2.mean = a.mean2; b2.rstd = a.rstd2; b2.gamma = w.ln2_g; b2.lddres = d;
+    if (m->lp_grad) b2.dres_lp = t.dsel_lp; else { b2.dres = t.dsel; b2.dx = t.dsel; }
+    b2.lddx = d; b2.dx_lp = t.dsel_lp; b2.lddx_lp = d; b2.rows = S; b2.d = d;
+    TRY(launch_ln_bwd(dt, b2, s));  // t.dsel(_lp) = gradient w.r.t. x_mid on the selected rows
+    GemmArgs g3; g3.A = t.dsel_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = S; g3.N = d; g3.K = d; g3.out0 = t.dattn_sel; g3.ldo0 = d;
+    TRY(gemm_call(m, EPI_STORE, g3, s));
+    // attention backward over all keys: d(attention output) is zero except on the selected query rows
+    HIP_TRY(hipMemsetAsync(t.dattn, 0, (size_t)M * d * esz, s));
+    TRY(launch_scatter_rows(t.dattn_sel, (size_t)d * esz, t.tail_rows, t.dattn, (size_t)d * esz, S, d * (int)esz, s));
+    AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.dout = t.dattn; at.dqkv = t.dqkv; at.delta = t.delta; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
+    TRY(launch_attn_bwd(dt, at, s));
+    GemmArgs g4; g4.A = t.dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 3 * d; g4.out0 = t.h; g4.ldo0 = d;
+    TRY(gemm_call(m, EPI_STORE, g4, s));
+    // the residual path into ln_1's input: d(x_mid), zero except on the selected rows
+    HIP_TRY(hipMemsetAsync(t.dx_lp, 0, (size_t)M * d * esz, s));
+    TRY(launch_scatter_rows(t.dsel_lp, (size_t)d * esz, t.tail_rows, t.dx_lp, (size_t)d * esz, S, d * (int)esz, s));
+    if (!m->lp_grad) {
+        HIP_TRY(hipMemsetAsync(t.dx, 0, (size_t)M * d * 4, s));
+        TRY(launch_scatter_rows(t.dsel, (size_t)d * 4, t.tail_rows, t.dx, (size_t)d * 4, S, d * 4, s));
+    }
+    LnBwdArgs b1; b1.dy = t.h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.lddres = d;
+    if (m->lp_grad) b1.dres_lp = t.dx_lp; else { b1.dres = t.dx; b1.dx = t.dx; }
+    b1.lddx = d; b1.dx_lp = t.dx_lp; b1.lddx_lp = d; b1.rows = M; b1.d = d;
+    TRY(launch_ln_bwd(dt, b1, s));
     return MUDPT_OK;
 }
 
@@ -549,7 +618,7 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
         for (int i = 0; i < m->txt.layers; ++i) {
             TRY(block_fwd(m, m->txt, i, C, (i >= 1 && i - 1 < D1) ? m->txt_deep + (size_t)(i - 1) * n * dt : nullptr, s2));
         }
-        LnFwdArgs lf; lf.x = m->txt.x_last; lf.ldx = dt; lf.row_index = m->eot_rows; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
+        LnFwdArgs lf; lf.x = m->txt.xout_sel; lf.ldx = dt; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
         lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = C; lf.d = dt;
         TRY(launch_ln_fwd(m->dtype, lf, s2));
         TRY(launch_sgemm(false, false, C, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f, e, nullptr, s2));
@@ -569,7 +638,7 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
     for (int i = 0; i < m->vis.layers; ++i) {
         TRY(block_fwd(m, m->vis, i, B, (i >= 1 && i - 1 < D1) ? m->vis_deep + (size_t)(i - 1) * n * dv : nullptr, s));
     }
-    LnFwdArgs lq; lq.x = m->vis.x_last; lq.ldx = dv; lq.row_index = m->cls_rows; lq.gamma = m->ln_post_g; lq.beta = m->ln_post_b; lq.out = m->f_ln; lq.ldo = dv;
+    LnFwdArgs lq; lq.x = m->vis.xout_sel; lq.ldx = dv; lq.gamma = m->ln_post_g; lq.beta = m->ln_post_b; lq.out = m->f_ln; lq.ldo = dv;
     lq.out_f32 = true; lq.mean = m->post_mean; lq.rstd = m->post_rstd; lq.rows = B; lq.d = dv;
     TRY(launch_ln_fwd(m->dtype, lq, s));
     TRY(launch_sgemm(false, false, B, e, dv, 1.f, m->f_ln, dv, m->vproj, e, 0.f, m->img_f, e, nullptr, s));
@@ -628,13 +697,11 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     HIP_TRY(hipStreamWaitEvent(s2, m->ev_fork_b, 0));
     Tower& X = m->txt;
     TRY(launch_sgemm(false, true, C, dt, e, 1.f, m->dtxt, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s2));
-    if (!m->lp_grad) HIP_TRY(hipMemsetAsync(X.dx, 0, (size_t)C * Lt * dt * 4, s2));
-    HIP_TRY(hipMemsetAsync(X.dx_lp, 0, (size_t)C * Lt * dt * 2, s2));
-    LnBwdArgs bf; bf.dy = m->dt_ln; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.x_last; bf.ldx = dt; bf.row_index = m->eot_rows; bf.mean = m->fin_mean; bf.rstd = m->fin_rstd;
-    bf.gamma = m->ln_fin_g; bf.dx = m->lp_grad ? nullptr : X.dx; bf.lddx = dt; bf.dx_lp = X.dx_lp; bf.lddx_lp = dt; bf.rows = C; bf.d = dt;
+    LnBwdArgs bf; bf.dy = m->dt_ln; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.xout_sel; bf.ldx = dt; bf.mean = m->fin_mean; bf.rstd = m->fin_rstd;
+    bf.gamma = m->ln_fin_g; bf.dx = m->lp_grad ? nullptr : X.dsel; bf.lddx = dt; bf.dx_lp = X.dsel_lp; bf.lddx_lp = dt; bf.rows = C; bf.d = dt;
     TRY(launch_ln_bwd(m->dtype, bf, s2));
     for (int i = X.layers - 1; i >= 0; --i) {
-        TRY(block_bwd(m, X, i, C, s2));
+        if (i == X.layers - 1) TRY(block_bwd_tail(m, X, C, s2)); else TRY(block_bwd(m, X, i, C, s2));
         if (i >= 1 && i - 1 < D1)
             TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, X.dx_lp, C, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, unscale, s2));
     }
@@ -645,13 +712,11 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     // -- vision tower backward
     Tower& V = m->vis;
     TRY(launch_sgemm(false, true, B, dv, e, 1.f, m->dimg, e, m->vproj, e, 0.f, m->df_ln, dv, nullptr, s));
-    if (!m->lp_grad) HIP_TRY(hipMemsetAsync(V.dx, 0, (size_t)B * Lv * dv * 4, s));
-    HIP_TRY(hipMemsetAsync(V.dx_lp, 0, (size_t)B * Lv * dv * 2, s));
-    LnBwdArgs bq; bq.dy = m->df_ln; bq.lddy = dv; bq.dy_f32 = true; bq.x = V.x_last; bq.ldx = dv; bq.row_index = m->cls_rows; bq.mean = m->post_mean; bq.rstd = m->post_rstd;
-    bq.gamma = m->ln_post_g; bq.dx = m->lp_grad ? nullptr : V.dx; bq.lddx = dv; bq.dx_lp = V.dx_lp; bq.lddx_lp = dv; bq.rows = B; bq.d = dv;
+    LnBwdArgs bq; bq.dy = m->df_ln; bq.lddy = dv; bq.dy_f32 = true; bq.x = V.xout_sel; bq.ldx = dv; bq.mean = m->post_mean; bq.rstd = m->post_rstd;
+    bq.gamma = m->ln_post_g; bq.dx = m->lp_grad ? nullptr : V.dsel; bq.lddx = dv; bq.dx_lp = V.dsel_lp; bq.lddx_lp = dv; bq.rows = B; bq.d = dv;
     TRY(launch_ln_bwd(m->dtype, bq, s));
     for (int i = V.layers - 1; i >= 0; --i) {
-        TRY(block_bwd(m, V, i, B, s));
+        if (i == V.layers - 1) TRY(block_bwd_tail(m, V, B, s)); else TRY(block_bwd(m, V, i, B, s));
         if (i >= 1 && i - 1 < D1)  // backward of the splice: prompt rows feed d(vis_deep[i-1]); the overwritten rows get no gradient
             TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : V.dx, V.dx_lp, B, Lv, dv, Lv - n, n, m->d_vis_deep + (size_t)(i - 1) * n * dv, true, false, unscale, s));
     }
@@ -749,7 +814,7 @@ extern "C" int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch,
     size_t n = 0;
     auto tower = [&](Tower& t, const std::string& rest, int nseq) {
         n = (size_t)nseq * t.L * t.d;
-        if (rest == "x_out") src = t.x_last;
+        if (rest == "x_out") { src = t.xout_sel; n = (size_t)nseq * t.d; }  // the used row (CLS / EOT) of every sequence only
         else if (rest.rfind("x_in.", 0) == 0) {
             const int i = atoi(rest.c_str() + 5);
             if (i >= 0 && i < t.layers) src = t.a[i].x_in;
