@@ -69,6 +69,7 @@ struct LnBwdArgs {
     void* dx_lp = nullptr; int lddx_lp = 0;   // optional T copy of the result
     int rows = 0, d = 0;
     bool by_token = false;  // dy / mean / rstd rows are indexed by the token row (row_index[r]) instead of r
+    bool stats_by_token = false;  // only mean / rstd are indexed by the token row; dy stays compact (row r)
 };
 int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s);
 

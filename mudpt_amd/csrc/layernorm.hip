@@ -83,8 +83,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     const size_t t = p.row_index ? (size_t)p.row_index[r] : (size_t)r;
     const f32x4* x = (const f32x4*)(p.x + t * p.ldx);
     const int d4 = p.d >> 2;
-    const size_t sr = p.by_token ? t : (size_t)r;  // row of dy / statistics
-    const float mean = p.mean[sr], rstd = p.rstd[sr];
+    const size_t sr = p.by_token ? t : (size_t)r;  // row of dy
+    const size_t st = (p.by_token || p.stats_by_token) ? t : (size_t)r;  // row of the statistics
+    const float mean = p.mean[st], rstd = p.rstd[st];
     f32x4 xh[LN_MAXV], g[LN_MAXV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll

@@ -86,6 +86,11 @@ struct Tower {
     float *xin_sel = nullptr, *xmid_sel = nullptr, *xout_sel = nullptr;  // fp32 [S, d]
     void *attn_sel = nullptr, *h_sel = nullptr, *u_sel = nullptr, *g_sel = nullptr, *dattn_sel = nullptr;  // T
     float* dsel = nullptr; void* dsel_lp = nullptr;  // gradient of the residual stream on the selected rows (fp32 / T)
+    // Head of the backward pass: block 0's input gradient is only needed on the n_ctx prompt rows of every sequence (the
+    // other rows of the tower input have no trainable ancestor), so its in_proj dX GEMM and ln_1 backward run on those rows.
+    const int* head_rows = nullptr;  // [nseq * n_ctx] token rows of the prompt tokens
+    int head_n = 0;                  // rows per sequence
+    void *hd_dqkv = nullptr, *hd_h = nullptr;  // T [max_seq * n_ctx, 3 d], [max_seq * n_ctx, d]
 };
 
 }  // namespace mudpt
@@ -112,7 +117,7 @@ struct mudpt_model {
     // text stem / head
     float *tpos = nullptr, *ln_fin_g = nullptr, *ln_fin_b = nullptr, *tproj = nullptr;
     float* emb_pos = nullptr;  // [C, Lt, dt] class token embeddings + positional embedding
-    int* eot_rows = nullptr;
+    int *eot_rows = nullptr, *tprompt_rows = nullptr;
     float *t_ln = nullptr, *fin_mean = nullptr, *fin_rstd = nullptr, *dt_ln = nullptr;
     float scale = 1.f;
     // prompt learner intermediates (fp32)
@@ -223,6 +228,8 @@ static int alloc_tower(mudpt_model* m, Tower& t, int d, int layers, int heads, i
     ALLOC(t.xin_sel, S * d * 4); ALLOC(t.xmid_sel, S * d * 4); ALLOC(t.xout_sel, S * d * 4);
     ALLOC(t.attn_sel, S * d * 2); ALLOC(t.h_sel, S * d * 2); ALLOC(t.u_sel, S * 4 * d * 2); ALLOC(t.g_sel, S * 4 * d * 2); ALLOC(t.dattn_sel, S * d * 2);
     ALLOC(t.dsel, S * d * 4); ALLOC(t.dsel_lp, S * d * 2);
+    t.head_n = m->cfg.n_ctx;
+    ALLOC(t.hd_dqkv, S * t.head_n * 3 * d * 2); ALLOC(t.hd_h, S * t.head_n * d * 2);
     return MUDPT_OK;
 }
 
@@ -292,6 +299,13 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
         }
         HIP_TRY(hipMemcpy(m->cls_rows, cr.data(), cr.size() * 4, hipMemcpyHostToDevice));
         m->vis.tail_rows = m->cls_rows;
+        m->vis.head_rows = m->vprompt_rows;
+        std::vector<int> tr((size_t)C * n);
+        for (int cc = 0; cc < C; ++cc)
+            for (int i = 0; i < n; ++i) tr[(size_t)cc * n + i] = cc * c->ctx_len + 1 + i;  // ctx rows 1..n (trainers/mudpt.py:97-115)
+        ALLOC(m->tprompt_rows, tr.size() * 4);
+        HIP_TRY(hipMemcpy(m->tprompt_rows, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
+        m->txt.head_rows = m->tprompt_rows;
         m->txt.tail_rows = m->eot_rows;  // filled by mudpt_set_class_prompts
         HIP_TRY(hipMemcpy(m->vprompt_rows, pr.data(), pr.size() * 4, hipMemcpyHostToDevice));
         return MUDPT_OK;
@@ -582,6 +596,20 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
     TRY(gemm_call(m, EPI_STORE, g3, s));
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.dout = t.dattn; at.dqkv = t.dqkv; at.delta = t.delta; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
     TRY(launch_attn_bwd(dt, at, s));
+    if (i == 0 && t.head_rows && t.layers > 1) {
+        // block 0: d(x_in) on the prompt rows only (Tower::head_rows); the other rows of t.dx / t.dx_lp are left stale and
+        // nothing reads them (the splice reductions and ln_pre's backward touch prompt rows only)
+        const int R = nseq * t.head_n;
+        TRY(launch_gather_rows(t.dqkv, (size_t)3 * d * 2, t.head_rows, t.hd_dqkv, (size_t)3 * d * 2, R, 3 * d * 2, s));
+        GemmArgs g4; g4.A = t.hd_dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = R; g4.N = d; g4.K = 3 * d; g4.out0 = t.hd_h; g4.ldo0 = d;
+        TRY(gemm_call(m, EPI_STORE, g4, s));
+        LnBwdArgs b1; b1.dy = t.hd_h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.row_index = t.head_rows; b1.stats_by_token = true;
+        b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.lddres = d;
+        if (m->lp_grad) b1.dres_lp = t.dx_lp; else { b1.dres = t.dx; b1.dx = t.dx; }
+        b1.lddx = d; b1.dx_lp = t.dx_lp; b1.lddx_lp = d; b1.rows = R; b1.d = d;
+        TRY(launch_ln_bwd(dt, b1, s));
+        return MUDPT_OK;
+    }
     GemmArgs g4; g4.A = t.dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 3 * d; g4.out0 = t.h; g4.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g4, s));
     LnBwdArgs b1; b1.dy = t.h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.lddres = d;
