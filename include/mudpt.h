@@ -12,6 +12,12 @@
  *   mudpt_forward_backward               trainers/mudpt.py:249-251 forward, F.cross_entropy, backward
  *   mudpt_sgd_step                       trainers/mudpt.py:251     model_backward_and_update's optimizer step
  *   mudpt_gemm / _layernorm_* / _attention_*   the ATen ops under clip/model.py:164-175,257-301 (unit parity)
+ * With mudpt_config.variant = MUDPT_VARIANT_COCOOP the same entry points run the CoCoOp path (trainers/cocoop.py):
+ *   mudpt_create / mudpt_set_weight      trainers/cocoop.py:22-40  load_clip_to_cpu: vanilla CLIP (clip/model.py:443-496 ViT)
+ *   mudpt_set_class_prompts              trainers/cocoop.py:113-122 token_prefix / token_suffix, tokenized_prompts
+ *   mudpt_param_*                        trainers/cocoop.py:96-107,222-226  ctx + meta_net.linear1/2 (5 tensors)
+ *   mudpt_forward                        trainers/cocoop.py:178-198 CustomCLIP.forward in eval mode (logits [B, C])
+ *   mudpt_forward_backward               trainers/cocoop.py:196-197,258-261 cross-entropy inside forward + backward
  *
  * Conventions: every function returns 0 on success or a MUDPT_ERR_* code; mudpt_last_error() gives
  * the message of the calling thread's last failure.  No exceptions cross the ABI.  A model handle is
@@ -28,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MUDPT_ABI_VERSION 1
+#define MUDPT_ABI_VERSION 2
 
 #define MUDPT_OK 0
 #define MUDPT_ERR_ARG 1   /* bad argument / shape (the reference raises AssertionError, mudpt.py:52,55,190) */
@@ -38,7 +44,10 @@ extern "C" {
 #define MUDPT_BF16 0
 #define MUDPT_F16 1
 
-/* Model shape.  ViT-B/16 MuDPT: {224,16,768,12,12, 512,12,8,77, 512, 4,12, n_cls, max_batch, dtype}. */
+#define MUDPT_VARIANT_MUDPT 0  /* trainers/mudpt.py: deep multi-modal prompts, 10 trainables */
+#define MUDPT_VARIANT_COCOOP 1 /* trainers/cocoop.py: instance-conditioned text prompts, 5 trainables; depth is ignored */
+
+/* Model shape.  ViT-B/16 MuDPT: {224,16,768,12,12, 512,12,8,77, 512, 4,12, n_cls, max_batch, dtype, 0}. */
 typedef struct mudpt_config {
     int32_t image_size, patch, v_width, v_layers, v_heads;
     int32_t t_width, t_layers, t_heads, ctx_len;
@@ -47,6 +56,7 @@ typedef struct mudpt_config {
     int32_t n_cls;        /* number of class prompts */
     int32_t max_batch;    /* activations are sized for this many images */
     int32_t dtype;        /* MUDPT_BF16 / MUDPT_F16: MFMA operand type (fp32 accumulate, fp32 residual stream) */
+    int32_t variant;      /* MUDPT_VARIANT_*; CoCoOp runs max_batch * n_cls text sequences per step */
 } mudpt_config;
 
 typedef struct mudpt_model mudpt_model;
@@ -67,7 +77,7 @@ int mudpt_set_weight(mudpt_model* m, const char* key, const float* host_data, si
 int mudpt_set_class_prompts(mudpt_model* m, const float* embedding, const int32_t* eot_index);
 
 /* The 10 trainable tensors live in ONE flat fp32 bucket (= the data-parallel all-reduce payload). */
-int mudpt_param_count(const mudpt_model* m);   /* 10 */
+int mudpt_param_count(const mudpt_model* m);   /* 10 (MuDPT) or 5 (CoCoOp) */
 size_t mudpt_param_numel(const mudpt_model* m); /* elements of the flat bucket */
 /* name = the reference's CustomCLIP state-dict key; shape has ndim entries (ndim <= 3). */
 int mudpt_param_info(const mudpt_model* m, int index, const char** name, size_t* offset, size_t* numel,

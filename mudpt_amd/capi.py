@@ -10,6 +10,8 @@ LIB_PATH = os.path.join(HERE, "lib", "libmudpt_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "mudpt.h")
 
 BF16, F16 = 0, 1
+VARIANT_MUDPT, VARIANT_COCOOP = 0, 1
+ABI_VERSION = 2
 EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD, EPI_PATCH, EPI_STORE_F32 = range(6)
 
 
@@ -20,7 +22,7 @@ class MudptError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "image_size", "patch", "v_width", "v_layers", "v_heads", "t_width", "t_layers", "t_heads", "ctx_len",
-        "embed_dim", "n_ctx", "depth", "n_cls", "max_batch", "dtype")]
+        "embed_dim", "n_ctx", "depth", "n_cls", "max_batch", "dtype", "variant")]
 
 
 _vp, _i32, _f32, _sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t

@@ -263,6 +263,13 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, 
     if (threadIdx.x == 0) out[0] = part[0] / n;
 }
 
+int launch_l2norm(const float* x, float* y, float* inv, int rows, int e, hipStream_t s) {
+    ARG_CHECK(x && y && inv && rows > 0 && e > 0, "l2norm: bad arguments");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, inv, rows, e);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
 static int check_head(const HeadArgs& a) {
     ARG_CHECK(a.img && a.txt && a.logits && a.img_n && a.txt_n && a.img_inv && a.txt_inv, "head: null operand");
     ARG_CHECK(a.B > 0 && a.C > 0 && a.e > 0, "head: bad shape B=%d C=%d e=%d", a.B, a.C, a.e);
@@ -289,6 +296,114 @@ int launch_head_bwd(const HeadArgs& a, hipStream_t s) {
     if (int e = launch_sgemm(true, false, a.C, a.e, a.B, a.scale, a.dlogits, a.C, a.img_n, a.e, 0.f, a.dtxt, a.e, nullptr, s)) return e;
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a.dimg, a.img_n, a.img_inv, a.B, a.e);
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((a.C + 3) / 4), dim3(256), 0, s, a.dtxt, a.txt_n, a.txt_inv, a.C, a.e);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+// ---- CoCoOp head: every image has its OWN text features (trainers/cocoop.py:187-196) ---------------------------------
+// logits[i, c] = scale * <img_n[i], txt_n[i * C + c]>   (one wave per (i, c))
+__global__ __launch_bounds__(256) void pair_logits_kernel(const float* __restrict__ img_n, const float* __restrict__ txt_n, float* __restrict__ logits,
+                                                          int B, int C, int e, float scale) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * C) return;
+    const float* a = img_n + (size_t)(r / C) * e;
+    const float* t = txt_n + (size_t)r * e;
+    float s = 0.f;
+    for (int k = lane; k < e; k += 64) s += a[k] * t[k];
+    s = wave_sum(s);
+    if (lane == 0) logits[r] = scale * s;
+}
+// d txt_n[i * C + c, :] = scale * dlogits[i, c] * img_n[i, :]
+__global__ __launch_bounds__(256) void pair_dtxt_kernel(const float* __restrict__ dlogits, const float* __restrict__ img_n, float* __restrict__ dtxt,
+                                                        int B, int C, int e, float scale) {
+    const int r = blockIdx.x;
+    const float g = scale * dlogits[r];
+    const float* a = img_n + (size_t)(r / C) * e;
+    for (int k = threadIdx.x; k < e; k += blockDim.x) dtxt[(size_t)r * e + k] = g * a[k];
+}
+
+// a.txt / txt_n / txt_inv / dtxt have B * C rows (row i * C + c); a.dimg is not produced (the image encoder is frozen and
+// meta_net's input is a constant of the step: nothing upstream of the image features trains, trainers/cocoop.py:222-226)
+int launch_pair_head_fwd(const HeadArgs& a, hipStream_t s) {
+    if (int e = check_head(a)) return e;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a.img, a.img_n, a.img_inv, a.B, a.e);
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((a.B * a.C + 3) / 4), dim3(256), 0, s, a.txt, a.txt_n, a.txt_inv, a.B * a.C, a.e);
+    hipLaunchKernelGGL(pair_logits_kernel, dim3((a.B * a.C + 3) / 4), dim3(256), 0, s, a.img_n, a.txt_n, a.logits, a.B, a.C, a.e, a.scale);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+int launch_pair_head_bwd(const HeadArgs& a, hipStream_t s) {
+    if (int e = check_head(a)) return e;
+    ARG_CHECK(a.labels && a.loss && a.dlogits && a.row_loss && a.dtxt, "pair head bwd: null operand");
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a.logits, a.labels, a.row_loss, a.dlogits, a.B, a.C, a.grad_scale / a.B);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, a.row_loss, a.B, a.loss);
+    hipLaunchKernelGGL(pair_dtxt_kernel, dim3(a.B * a.C), dim3(128), 0, s, a.dlogits, a.img_n, a.dtxt, a.B, a.C, a.e, a.scale);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((a.B * a.C + 3) / 4), dim3(256), 0, s, a.dtxt, a.txt_n, a.txt_inv, a.B * a.C, a.e);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+// ---- CoCoOp prompt construction (trainers/cocoop.py:148-165) + positional embedding (:52) ---------------------------------
+// x0[(i, c), l, :] = emb_pos[c, l, :] for l outside 1..n;  = ctx[l-1] + bias[i] + pos[l] for the n context rows
+__global__ __launch_bounds__(128) void cocoop_prompts_kernel(float* __restrict__ x0, const float* __restrict__ emb_pos, const float* __restrict__ ctx,
+                                                             const float* __restrict__ bias, const float* __restrict__ pos, int C, int L, int d, int n) {
+    const int row = blockIdx.x;  // (i * C + c) * L + l
+    const int l = row % L, seq = row / L, c = seq % C, i = seq / C;
+    f32x4* dst = (f32x4*)(x0 + (size_t)row * d);
+    if (l >= 1 && l <= n) {
+        const f32x4 *a = (const f32x4*)(ctx + (size_t)(l - 1) * d), *b = (const f32x4*)(bias + (size_t)i * d), *p = (const f32x4*)(pos + (size_t)l * d);
+        for (int k = threadIdx.x; k < d / 4; k += blockDim.x) dst[k] = a[k] + b[k] + p[k];
+    } else {
+        const f32x4* src = (const f32x4*)(emb_pos + ((size_t)c * L + l) * d);
+        for (int k = threadIdx.x; k < d / 4; k += blockDim.x) dst[k] = src[k];
+    }
+}
+int launch_cocoop_prompts(float* x0, const float* emb_pos, const float* ctx, const float* bias, const float* pos, int B, int C, int L, int d, int n, hipStream_t s) {
+    ARG_CHECK(x0 && emb_pos && ctx && bias && pos && B > 0 && C > 0 && n > 0 && 1 + n < L && d % 4 == 0, "cocoop_prompts: bad arguments");
+    hipLaunchKernelGGL(cocoop_prompts_kernel, dim3(B * C * L), dim3(128), 0, s, x0, emb_pos, ctx, bias, pos, C, L, d, n);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+// d bias[i, :] = scale * sum_c sum_r dx[(i, c), 1 + r, :]  (c, then r ascending: a fixed order, bitwise reproducible)
+template <typename T>
+__global__ __launch_bounds__(128) void cocoop_dbias_kernel(const float* __restrict__ dx, const typename T::elem* __restrict__ dx_lp, float* __restrict__ dbias,
+                                                           int C, int L, int d, int n, float scale) {
+    const int i = blockIdx.x;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c)
+            for (int r = 0; r < n; ++r) {
+                const size_t o = (((size_t)i * C + c) * L + 1 + r) * d + k;
+                acc += dx ? dx[o] : (float)dx_lp[o];
+            }
+        dbias[(size_t)i * d + k] = acc * scale;
+    }
+}
+int launch_cocoop_dbias(int dtype, const float* dx, const void* dx_lp, float* dbias, int B, int C, int L, int d, int n, float scale, hipStream_t s) {
+    ARG_CHECK((dx || dx_lp) && dbias && B > 0 && C > 0 && n > 0 && 1 + n < L, "cocoop_dbias: bad arguments");
+    if (dtype == DT_BF16) hipLaunchKernelGGL(cocoop_dbias_kernel<BF16>, dim3(B), dim3(128), 0, s, dx, (const __bf16*)dx_lp, dbias, C, L, d, n, scale);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(cocoop_dbias_kernel<F16>, dim3(B), dim3(128), 0, s, dx, (const _Float16*)dx_lp, dbias, C, L, d, n, scale);
+    else { set_error("cocoop_dbias: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+// ReLU in place, and its backward: dy *= (y > 0)   (meta_net, trainers/cocoop.py:103-107)
+__global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ y, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fmaxf(y[i], 0.f);
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) dy[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+int launch_relu(float* y, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(relu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+int launch_relu_bwd(float* dy, const float* y, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, y, n);
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
 }

@@ -134,6 +134,17 @@ struct HeadArgs {
 };
 int launch_head_fwd(const HeadArgs& a, hipStream_t s);
 int launch_head_bwd(const HeadArgs& a, hipStream_t s);
+// CoCoOp (trainers/cocoop.py): per-image text features.  txt / txt_n / txt_inv / dtxt have B * C rows (row i * C + c).
+int launch_pair_head_fwd(const HeadArgs& a, hipStream_t s);
+int launch_pair_head_bwd(const HeadArgs& a, hipStream_t s);  // loss, dlogits, dtxt (gradient of the raw text features)
+// text-tower input of every (image, class) pair: class prompt + positional embedding, context rows = ctx + meta_net(image) + pos
+int launch_cocoop_prompts(float* x0, const float* emb_pos, const float* ctx, const float* bias, const float* pos, int B, int C, int L, int d, int n, hipStream_t s);
+// d bias[i] = scale * sum over the classes and the n context rows of the text-input gradient (fp32 dx or its T copy)
+int launch_cocoop_dbias(int dtype, const float* dx, const void* dx_lp, float* dbias, int B, int C, int L, int d, int n, float scale, hipStream_t s);
+// y = x / ||x|| per row, inv = 1 / ||x||
+int launch_l2norm(const float* x, float* y, float* inv, int rows, int e, hipStream_t s);
+int launch_relu(float* y, size_t n, hipStream_t s);
+int launch_relu_bwd(float* dy, const float* y, size_t n, hipStream_t s);
 // Fused SGD (torch.optim.SGD semantics) over the flat bucket.
 int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
                float dampening, bool nesterov, bool first_step, hipStream_t s);

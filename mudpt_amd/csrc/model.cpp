@@ -132,6 +132,11 @@ struct mudpt_model {
     size_t off[10];
     size_t numel[10];
     size_t total = 0;
+    // CoCoOp variant (trainers/cocoop.py): 5 trainables, vanilla vision tower (forward only), B * C text sequences
+    bool cocoop = false;
+    int nparams = 10;
+    int hid = 0;  // meta_net hidden width = embed_dim / 16 (trainers/cocoop.py:104)
+    float *mn_hid = nullptr, *mn_bias = nullptr, *mn_dbias = nullptr, *mn_dhid = nullptr;  // [B, hid], [B, dt], [B, dt], [B, hid]
     float loss_scale = 128.f;  // static, power of two; see mudpt_forward_backward
     // bf16 mode keeps the gradient of the residual stream in T only (the fp32 copy costs 237 MB of HBM traffic per
     // LayerNorm backward); fp16 mode -- the parity configuration -- keeps it in fp32.  mudpt_debug_set("lp_grad") overrides.
@@ -184,6 +189,15 @@ static const char* kParamNames[10] = {
     "image_encoder.visual_ctx_deep_projections.bias",
 };
 enum { P_CTX = 0, P_DEEP, P_EW, P_EB, P_DW, P_DB, P_VCTX, P_VDEEP, P_VW, P_VB };
+// CoCoOp: names under CustomCLIP (trainers/cocoop.py:96-107,176; the reference registers the prompt_learner sub-module)
+static const char* kCocoopNames[5] = {
+    "prompt_learner.ctx",
+    "prompt_learner.meta_net.linear1.weight",
+    "prompt_learner.meta_net.linear1.bias",
+    "prompt_learner.meta_net.linear2.weight",
+    "prompt_learner.meta_net.linear2.bias",
+};
+enum { Q_CTX = 0, Q_W1, Q_B1, Q_W2, Q_B2 };
 
 
 static int dev_alloc(mudpt_model* m, void** out, size_t bytes) {
@@ -247,7 +261,9 @@ extern "C" const char* mudpt_last_error(void) { return get_error(); }
 extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     ARG_CHECK(c && out, "create: null argument");
     ARG_CHECK(c->dtype == MUDPT_BF16 || c->dtype == MUDPT_F16, "create: dtype must be MUDPT_BF16 or MUDPT_F16");
-    ARG_CHECK(c->depth > 0, "PROMPT_DEPTH should be > 0");  // trainers/mudpt.py:52
+    ARG_CHECK(c->variant == MUDPT_VARIANT_MUDPT || c->variant == MUDPT_VARIANT_COCOOP, "create: unknown variant %d", c->variant);
+    const bool cocoop = c->variant == MUDPT_VARIANT_COCOOP;
+    ARG_CHECK(cocoop || c->depth > 0, "PROMPT_DEPTH should be > 0");  // trainers/mudpt.py:52
     ARG_CHECK(c->n_ctx > 0 && c->n_cls > 0 && c->max_batch > 0, "create: n_ctx, n_cls, max_batch must be positive");
     ARG_CHECK(c->image_size % c->patch == 0 && c->patch % 8 == 0, "create: image_size %d / patch %d unsupported", c->image_size, c->patch);
     ARG_CHECK(c->v_width == c->v_heads * 64 && c->t_width == c->t_heads * 64, "create: head dim must be 64");
@@ -256,17 +272,20 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     ARG_CHECK((3 * c->patch * c->patch) % 64 == 0, "create: 3*patch^2 must be a multiple of 64");
     ARG_CHECK(1 + c->n_ctx < c->ctx_len, "create: n_ctx too large for ctx_len");
     const int P = (c->image_size / c->patch) * (c->image_size / c->patch);
-    const int Lv = 1 + P + c->n_ctx;
+    const int Lv = 1 + P + (cocoop ? 0 : c->n_ctx);  // CoCoOp's image encoder is the vanilla ViT (trainers/cocoop.py:38, clip/model.py:443-496)
     ARG_CHECK(Lv <= 224 && c->ctx_len <= 224, "create: sequence length %d/%d exceeds the on-chip attention limit (224)", Lv, c->ctx_len);
 
     mudpt_model* m = new mudpt_model();
     m->cfg = *c;
     m->dtype = c->dtype;
     m->lp_grad = (c->dtype == MUDPT_BF16) && g_lp_grad_default;
-    const int dv = c->v_width, dt = c->t_width, e = c->embed_dim, n = c->n_ctx, D1 = c->depth - 1, B = c->max_batch, C = c->n_cls;
+    m->cocoop = cocoop;
+    if (cocoop) m->cfg.depth = 1;  // no deep prompts
+    const int dv = c->v_width, dt = c->t_width, e = c->embed_dim, n = c->n_ctx, D1 = m->cfg.depth - 1, B = c->max_batch, C = c->n_cls;
+    const int TS = cocoop ? B * C : C;  // text sequences per step: one per (image, class) pair in CoCoOp (trainers/cocoop.py:187-194)
     auto fail = [&](int code) { mudpt_destroy(m); return code; };
-    if (int r = alloc_tower(m, m->vis, dv, c->v_layers, c->v_heads, Lv, B, false, Lv - n)) return fail(r);
-    if (int r = alloc_tower(m, m->txt, dt, c->t_layers, c->t_heads, c->ctx_len, C, true, 1)) return fail(r);
+    if (int r = alloc_tower(m, m->vis, dv, c->v_layers, c->v_heads, Lv, B, false, cocoop ? Lv : Lv - n)) return fail(r);
+    if (int r = alloc_tower(m, m->txt, dt, c->t_layers, c->t_heads, c->ctx_len, TS, true, 1)) return fail(r);
     auto body = [&]() -> int {
         const int K0 = 3 * c->patch * c->patch;
         ALLOC(m->conv_w, (size_t)dv * K0 * 2);
@@ -279,16 +298,21 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
         ALLOC(m->cls_rows, B * 4); ALLOC(m->vprompt_rows, (size_t)B * n * 4);
         ALLOC(m->tpos, (size_t)c->ctx_len * dt * 4); ALLOC(m->ln_fin_g, dt * 4); ALLOC(m->ln_fin_b, dt * 4);
         ALLOC(m->tproj, (size_t)dt * e * 4);
-        ALLOC(m->emb_pos, (size_t)C * c->ctx_len * dt * 4); ALLOC(m->eot_rows, C * 4);
-        ALLOC(m->t_ln, (size_t)C * dt * 4); ALLOC(m->fin_mean, C * 4); ALLOC(m->fin_rstd, C * 4); ALLOC(m->dt_ln, (size_t)C * dt * 4);
+        ALLOC(m->emb_pos, (size_t)C * c->ctx_len * dt * 4); ALLOC(m->eot_rows, TS * 4);
+        ALLOC(m->t_ln, (size_t)TS * dt * 4); ALLOC(m->fin_mean, TS * 4); ALLOC(m->fin_rstd, TS * 4); ALLOC(m->dt_ln, (size_t)TS * dt * 4);
         const size_t dn = (size_t)(D1 > 0 ? D1 : 1) * n;
         ALLOC(m->shared, (size_t)n * dv * 4); ALLOC(m->t2v, dn * dv * 4); ALLOC(m->v2t, dn * e * 4);
         ALLOC(m->vis_deep, dn * dv * 4); ALLOC(m->txt_deep, dn * dt * 4);
         ALLOC(m->d_vis_deep, dn * dv * 4); ALLOC(m->d_txt_deep, dn * dt * 4); ALLOC(m->d_vprompt0, (size_t)n * dv * 4);
-        ALLOC(m->img_f, (size_t)B * e * 4); ALLOC(m->txt_f, (size_t)C * e * 4); ALLOC(m->img_n, (size_t)B * e * 4); ALLOC(m->txt_n, (size_t)C * e * 4);
-        ALLOC(m->img_inv, B * 4); ALLOC(m->txt_inv, C * 4);
+        ALLOC(m->img_f, (size_t)B * e * 4); ALLOC(m->txt_f, (size_t)TS * e * 4); ALLOC(m->img_n, (size_t)B * e * 4); ALLOC(m->txt_n, (size_t)TS * e * 4);
+        ALLOC(m->img_inv, B * 4); ALLOC(m->txt_inv, TS * 4);
         ALLOC(m->logits, (size_t)B * C * 4); ALLOC(m->dlogits, (size_t)B * C * 4); ALLOC(m->row_loss, B * 4);
-        ALLOC(m->dimg, (size_t)B * e * 4); ALLOC(m->dtxt, (size_t)C * e * 4); ALLOC(m->loss, 16);
+        ALLOC(m->dimg, (size_t)B * e * 4); ALLOC(m->dtxt, (size_t)TS * e * 4); ALLOC(m->loss, 16);
+        if (cocoop) {
+            m->hid = e / 16;
+            ALLOC(m->mn_hid, (size_t)B * m->hid * 4); ALLOC(m->mn_dhid, (size_t)B * m->hid * 4);
+            ALLOC(m->mn_bias, (size_t)B * dt * 4); ALLOC(m->mn_dbias, (size_t)B * dt * 4);
+        }
         HIP_TRY(hipStreamCreateWithFlags(&m->s2, hipStreamNonBlocking));
         for (hipEvent_t* e : {&m->ev_fork, &m->ev_join, &m->ev_fork_b, &m->ev_join_b}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
         // row index tables
@@ -299,9 +323,9 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
         }
         HIP_TRY(hipMemcpy(m->cls_rows, cr.data(), cr.size() * 4, hipMemcpyHostToDevice));
         m->vis.tail_rows = m->cls_rows;
-        m->vis.head_rows = m->vprompt_rows;
-        std::vector<int> tr((size_t)C * n);
-        for (int cc = 0; cc < C; ++cc)
+        m->vis.head_rows = cocoop ? nullptr : m->vprompt_rows;
+        std::vector<int> tr((size_t)TS * n);
+        for (int cc = 0; cc < TS; ++cc)
             for (int i = 0; i < n; ++i) tr[(size_t)cc * n + i] = cc * c->ctx_len + 1 + i;  // ctx rows 1..n (trainers/mudpt.py:97-115)
         ALLOC(m->tprompt_rows, tr.size() * 4);
         HIP_TRY(hipMemcpy(m->tprompt_rows, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
@@ -315,8 +339,11 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     // flat bucket layout, reference order/shapes: trainers/mudpt.py:71-81, clip/model.py:512-519
     const size_t shapes[10] = {(size_t)n * dt, (size_t)D1 * n * dt, (size_t)dv * dt, (size_t)dv, (size_t)dv * dt, (size_t)dv,
                                (size_t)n * dv, (size_t)D1 * n * dv, (size_t)e * dv, (size_t)e};
+    // CoCoOp: ctx [n, dt], meta_net.linear1 [e/16, e] + [e/16], meta_net.linear2 [dt, e/16] + [dt]  (trainers/cocoop.py:96-107)
+    const size_t cshapes[5] = {(size_t)n * dt, (size_t)(e / 16) * e, (size_t)(e / 16), (size_t)dt * (e / 16), (size_t)dt};
+    m->nparams = cocoop ? 5 : 10;
     size_t o = 0;
-    for (int i = 0; i < 10; ++i) { m->off[i] = o; m->numel[i] = shapes[i]; o += shapes[i]; }
+    for (int i = 0; i < m->nparams; ++i) { m->off[i] = o; m->numel[i] = cocoop ? cshapes[i] : shapes[i]; o += m->numel[i]; }
     m->total = o;
     if (int r = dev_alloc(m, (void**)&m->momentum, o * 4)) return fail(r);
 
@@ -432,10 +459,11 @@ extern "C" int mudpt_set_class_prompts(mudpt_model* m, const float* emb, const i
     const size_t C = c.n_cls, L = c.ctx_len, d = c.t_width;
     std::vector<float> pos(L * d), ep(C * L * d);
     HIP_TRY(hipMemcpy(pos.data(), m->tpos, pos.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<int> rows(C);
+    const size_t reps = m->cocoop ? (size_t)c.max_batch : 1;  // CoCoOp: sequence i * C + c for every image i
+    std::vector<int> rows(C * reps);
     for (size_t cc = 0; cc < C; ++cc) {
         ARG_CHECK(eot[cc] >= 0 && eot[cc] < (int)L, "set_class_prompts: eot index %d out of range", eot[cc]);
-        rows[cc] = (int)(cc * L) + eot[cc];
+        for (size_t i = 0; i < reps; ++i) rows[i * C + cc] = (int)((i * C + cc) * L) + eot[cc];
         for (size_t i = 0; i < L * d; ++i) ep[cc * L * d + i] = emb[cc * L * d + i] + pos[i];  // trainers/mudpt.py:143
     }
     HIP_TRY(hipMemcpy(m->emb_pos, ep.data(), ep.size() * 4, hipMemcpyHostToDevice));
@@ -444,12 +472,23 @@ extern "C" int mudpt_set_class_prompts(mudpt_model* m, const float* emb, const i
     return MUDPT_OK;
 }
 
-extern "C" int mudpt_param_count(const mudpt_model*) { return 10; }
+extern "C" int mudpt_param_count(const mudpt_model* m) { return m ? m->nparams : 0; }
 extern "C" size_t mudpt_param_numel(const mudpt_model* m) { return m ? m->total : 0; }
 extern "C" int mudpt_param_info(const mudpt_model* m, int i, const char** name, size_t* offset, size_t* numel, int32_t* ndim, int64_t shape[3]) {
-    ARG_CHECK(m && i >= 0 && i < 10, "param_info: bad index %d", i);
+    ARG_CHECK(m && i >= 0 && i < m->nparams, "param_info: bad index %d", i);
     const mudpt_config& c = m->cfg;
     const int64_t n = c.n_ctx, D1 = c.depth - 1, dt = c.t_width, dv = c.v_width, e = c.embed_dim;
+    if (m->cocoop) {
+        const int64_t hd = e / 16;
+        const int64_t cshp[5][3] = {{n, dt, 0}, {hd, e, 0}, {hd, 0, 0}, {dt, hd, 0}, {dt, 0, 0}};
+        const int cnd[5] = {2, 2, 1, 2, 1};
+        if (name) *name = kCocoopNames[i];
+        if (offset) *offset = m->off[i];
+        if (numel) *numel = m->numel[i];
+        if (ndim) *ndim = cnd[i];
+        if (shape) for (int k = 0; k < 3; ++k) shape[k] = cshp[i][k];
+        return MUDPT_OK;
+    }
     const int64_t shp[10][3] = {{n, dt, 0}, {D1, n, dt}, {dv, dt, 0}, {dv, 0, 0}, {dv, dt, 0}, {dv, 0, 0}, {n, dv, 0}, {D1, n, dv}, {e, dv, 0}, {e, 0, 0}};
     const int nd[10] = {2, 3, 2, 1, 2, 1, 2, 3, 2, 1};
     if (name) *name = kParamNames[i];
@@ -619,10 +658,99 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
     return MUDPT_OK;
 }
 
+// Vision tower forward, clip/model.py:526-553 (MuDPT: prompt rows appended before ln_pre, deep prompts spliced per block) or
+// clip/model.py:478-496 (CoCoOp: the vanilla ViT, no prompt rows) -> m->img_f [B, e]
+static int vision_forward(mudpt_model* m, const float* images, int B, hipStream_t s) {
+    const mudpt_config& c = m->cfg;
+    const int dv = c.v_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1;
+    const int P = (c.image_size / c.patch) * (c.image_size / c.patch), Lv = m->vis.L, K0 = 3 * c.patch * c.patch;
+    float* Pm = m->params;
+    TRY(launch_patchify(m->dtype, images, m->patches, B, c.image_size, c.patch, s));
+    GemmArgs pe; pe.A = m->patches; pe.lda = K0; pe.B = m->conv_w; pe.ldb = K0; pe.M = B * P; pe.N = dv; pe.K = K0; pe.out0 = m->xpre; pe.ldo0 = dv;
+    pe.patches = P; pe.seq_len = Lv; pe.pos = m->vpos;
+    TRY(gemm_call(m, EPI_PATCH, pe, s));
+    TRY(launch_set_rows(m->xpre, B, Lv, dv, 0, 1, m->cls, m->vpos, s));
+    if (!m->cocoop) TRY(launch_set_rows(m->xpre, B, Lv, dv, Lv - n, n, Pm + m->off[P_VCTX], m->shared, s));
+    LnFwdArgs lp; lp.x = m->xpre; lp.ldx = dv; lp.gamma = m->ln_pre_g; lp.beta = m->ln_pre_b; lp.out = m->vis.a[0].x_in; lp.ldo = dv; lp.out_f32 = true;
+    lp.mean = m->pre_mean; lp.rstd = m->pre_rstd; lp.rows = B * Lv; lp.d = dv;
+    TRY(launch_ln_fwd(m->dtype, lp, s));
+    for (int i = 0; i < m->vis.layers; ++i) {
+        TRY(block_fwd(m, m->vis, i, B, (i >= 1 && i - 1 < D1) ? m->vis_deep + (size_t)(i - 1) * n * dv : nullptr, s));
+    }
+    LnFwdArgs lq; lq.x = m->vis.xout_sel; lq.ldx = dv; lq.gamma = m->ln_post_g; lq.beta = m->ln_post_b; lq.out = m->f_ln; lq.ldo = dv;
+    lq.out_f32 = true; lq.mean = m->post_mean; lq.rstd = m->post_rstd; lq.rows = B; lq.d = dv;
+    TRY(launch_ln_fwd(m->dtype, lq, s));
+    TRY(launch_sgemm(false, false, B, e, dv, 1.f, m->f_ln, dv, m->vproj, e, 0.f, m->img_f, e, nullptr, s));
+    return MUDPT_OK;
+}
+
+// ---- CoCoOp (trainers/cocoop.py) ------------------------------------------------------------------------------------
+// forward (:178-198): image features of the frozen vanilla ViT -> meta_net bias per image (:141-146) -> one text-tower pass
+// over all B * C (image, class) prompts at once (the reference loops over the images, :187-194) -> logits [B, C].
+static int cocoop_forward(mudpt_model* m, const float* images, int B, hipStream_t s) {
+    const mudpt_config& c = m->cfg;
+    const int dt = c.t_width, e = c.embed_dim, n = c.n_ctx, C = c.n_cls, Lt = m->txt.L, hd = m->hid, TS = B * C;
+    float* Pm = m->params;
+    TRY(vision_forward(m, images, B, s));
+    // image_features / ||.|| (:183) feeds both meta_net and the logits
+    HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.scale = m->scale; h.logits = m->logits; h.img_n = m->img_n; h.txt_n = m->txt_n;
+    h.img_inv = m->img_inv; h.txt_inv = m->txt_inv; h.B = B; h.C = C; h.e = e;
+    // meta_net: linear1 -> ReLU -> linear2 (:103-107), fp32
+    TRY(launch_l2norm(m->img_f, m->img_n, m->img_inv, B, e, s));
+    TRY(launch_sgemm(false, true, B, hd, e, 1.f, m->img_n, e, Pm + m->off[Q_W1], e, 0.f, m->mn_hid, hd, Pm + m->off[Q_B1], s));
+    TRY(launch_relu(m->mn_hid, (size_t)B * hd, s));
+    TRY(launch_sgemm(false, true, B, dt, hd, 1.f, m->mn_hid, hd, Pm + m->off[Q_W2], hd, 0.f, m->mn_bias, dt, Pm + m->off[Q_B2], s));
+    // prompts (:148-165) + positional embedding (:52)
+    TRY(launch_cocoop_prompts(m->txt.a[0].x_in, m->emb_pos, Pm + m->off[Q_CTX], m->mn_bias, m->tpos, B, C, Lt, dt, n, s));
+    for (int i = 0; i < m->txt.layers; ++i) TRY(block_fwd(m, m->txt, i, TS, nullptr, s));
+    LnFwdArgs lf; lf.x = m->txt.xout_sel; lf.ldx = dt; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
+    lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = TS; lf.d = dt;
+    TRY(launch_ln_fwd(m->dtype, lf, s));
+    TRY(launch_sgemm(false, false, TS, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f, e, nullptr, s));
+    TRY(launch_pair_head_fwd(h, s));
+    return MUDPT_OK;
+}
+
+// forward + F.cross_entropy (:196-197) + backward w.r.t. ctx and meta_net (:222-226 freeze rule: "prompt_learner" only)
+static int cocoop_forward_backward(mudpt_model* m, const float* images, const int64_t* labels, int B, float grad_scale, float* loss, float* logits, hipStream_t s) {
+    const mudpt_config& c = m->cfg;
+    const int dt = c.t_width, e = c.embed_dim, n = c.n_ctx, C = c.n_cls, Lt = m->txt.L, hd = m->hid, TS = B * C;
+    float *Pm = m->params, *G = m->grads;
+    TRY(cocoop_forward(m, images, B, s));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(G, 0, m->total * 4, s));
+    HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.labels = labels; h.scale = m->scale; h.logits = m->logits; h.loss = m->loss; h.dlogits = m->dlogits;
+    h.row_loss = m->row_loss; h.dtxt = m->dtxt; h.img_n = m->img_n; h.txt_n = m->txt_n; h.img_inv = m->img_inv; h.txt_inv = m->txt_inv;
+    const float unscale = grad_scale / ((float)B * m->loss_scale);  // static loss scaling, as in mudpt_forward_backward
+    h.grad_scale = m->loss_scale * (float)B; h.B = B; h.C = C; h.e = e;
+    TRY(launch_pair_head_bwd(h, s));
+    HIP_TRY(hipMemcpyAsync(loss, m->loss, 4, hipMemcpyDeviceToDevice, s));
+    Tower& X = m->txt;
+    TRY(launch_sgemm(false, true, TS, dt, e, 1.f, m->dtxt, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s));
+    LnBwdArgs bf; bf.dy = m->dt_ln; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.xout_sel; bf.ldx = dt; bf.mean = m->fin_mean; bf.rstd = m->fin_rstd;
+    bf.gamma = m->ln_fin_g; bf.dx = m->lp_grad ? nullptr : X.dsel; bf.lddx = dt; bf.dx_lp = X.dsel_lp; bf.lddx_lp = dt; bf.rows = TS; bf.d = dt;
+    TRY(launch_ln_bwd(m->dtype, bf, s));
+    for (int i = X.layers - 1; i >= 0; --i) {
+        if (i == X.layers - 1) TRY(block_bwd_tail(m, X, TS, s)); else TRY(block_bwd(m, X, i, TS, s));
+    }
+    // d ctx = sum over all (image, class) prompts of the context rows' gradient; d bias[i] = the same sum over image i's prompts
+    TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, m->lp_grad ? X.dx_lp : nullptr, TS, Lt, dt, 1, n, G + m->off[Q_CTX], false, false, unscale, s));
+    TRY(launch_cocoop_dbias(m->dtype, m->lp_grad ? nullptr : X.dx, m->lp_grad ? X.dx_lp : nullptr, m->mn_dbias, B, C, Lt, dt, n, unscale, s));
+    // meta_net backward (fp32, tiny): linear2, ReLU, linear1; its input (the normalised image features) is a constant
+    TRY(launch_sgemm(true, false, dt, hd, B, 1.f, m->mn_dbias, dt, m->mn_hid, hd, 0.f, G + m->off[Q_W2], hd, nullptr, s));
+    TRY(launch_colsum(m->mn_dbias, B, dt, dt, G + m->off[Q_B2], false, s));
+    TRY(launch_sgemm(false, false, B, hd, dt, 1.f, m->mn_dbias, dt, Pm + m->off[Q_W2], hd, 0.f, m->mn_dhid, hd, nullptr, s));
+    TRY(launch_relu_bwd(m->mn_dhid, m->mn_hid, (size_t)B * hd, s));
+    TRY(launch_sgemm(true, false, hd, e, B, 1.f, m->mn_dhid, hd, m->img_n, e, 0.f, G + m->off[Q_W1], e, nullptr, s));
+    TRY(launch_colsum(m->mn_dhid, B, hd, hd, G + m->off[Q_B1], false, s));
+    return MUDPT_OK;
+}
+
 static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t s, bool reuse_text = false) {
+    if (m->cocoop) return cocoop_forward(m, images, B, s);
     const mudpt_config& c = m->cfg;
     const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, C = c.n_cls;
-    const int P = (c.image_size / c.patch) * (c.image_size / c.patch), Lv = m->vis.L, Lt = m->txt.L, K0 = 3 * c.patch * c.patch;
+    const int Lt = m->txt.L;
     float* Pm = m->params;
     // -- prompt learner, trainers/mudpt.py:117-130 + clip/model.py:534-539
     TRY(launch_sgemm(false, true, n, dv, dt, 1.f, Pm + m->off[P_CTX], dt, Pm + m->off[P_EW], dt, 0.f, m->shared, dv, Pm + m->off[P_EB], s));
@@ -654,22 +782,7 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
         m->text_valid = true;
     }
     // -- vision tower, clip/model.py:526-553
-    TRY(launch_patchify(m->dtype, images, m->patches, B, c.image_size, c.patch, s));
-    GemmArgs pe; pe.A = m->patches; pe.lda = K0; pe.B = m->conv_w; pe.ldb = K0; pe.M = B * P; pe.N = dv; pe.K = K0; pe.out0 = m->xpre; pe.ldo0 = dv;
-    pe.patches = P; pe.seq_len = Lv; pe.pos = m->vpos;
-    TRY(gemm_call(m, EPI_PATCH, pe, s));
-    TRY(launch_set_rows(m->xpre, B, Lv, dv, 0, 1, m->cls, m->vpos, s));
-    TRY(launch_set_rows(m->xpre, B, Lv, dv, Lv - n, n, Pm + m->off[P_VCTX], m->shared, s));
-    LnFwdArgs lp; lp.x = m->xpre; lp.ldx = dv; lp.gamma = m->ln_pre_g; lp.beta = m->ln_pre_b; lp.out = m->vis.a[0].x_in; lp.ldo = dv; lp.out_f32 = true;
-    lp.mean = m->pre_mean; lp.rstd = m->pre_rstd; lp.rows = B * Lv; lp.d = dv;
-    TRY(launch_ln_fwd(m->dtype, lp, s));
-    for (int i = 0; i < m->vis.layers; ++i) {
-        TRY(block_fwd(m, m->vis, i, B, (i >= 1 && i - 1 < D1) ? m->vis_deep + (size_t)(i - 1) * n * dv : nullptr, s));
-    }
-    LnFwdArgs lq; lq.x = m->vis.xout_sel; lq.ldx = dv; lq.gamma = m->ln_post_g; lq.beta = m->ln_post_b; lq.out = m->f_ln; lq.ldo = dv;
-    lq.out_f32 = true; lq.mean = m->post_mean; lq.rstd = m->post_rstd; lq.rows = B; lq.d = dv;
-    TRY(launch_ln_fwd(m->dtype, lq, s));
-    TRY(launch_sgemm(false, false, B, e, dv, 1.f, m->f_ln, dv, m->vproj, e, 0.f, m->img_f, e, nullptr, s));
+    TRY(vision_forward(m, images, B, s));
     // -- cosine logits, trainers/mudpt.py:178-182 (needs both towers)
     if (!reuse_text) HIP_TRY(hipStreamWaitEvent(s, m->ev_join, 0));
     HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.scale = m->scale; h.logits = m->logits; h.img_n = m->img_n; h.txt_n = m->txt_n;
@@ -686,7 +799,7 @@ extern "C" int mudpt_forward_ex(mudpt_model* m, const float* images, int32_t B, 
     TRY(ready(m, B, false));
     ARG_CHECK(images && logits, "forward: null argument");
     hipStream_t s = (hipStream_t)stream;
-    const bool reuse = (flags & MUDPT_FWD_REUSE_TEXT) != 0;
+    const bool reuse = (flags & MUDPT_FWD_REUSE_TEXT) != 0 && !m->cocoop;  // CoCoOp's text features depend on the image
     if (reuse && !m->text_valid) { set_error("forward: MUDPT_FWD_REUSE_TEXT before any text-tower pass"); return MUDPT_ERR_STATE; }
     TRY(forward_impl(m, images, B, s, reuse));
     HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * m->cfg.n_cls * 4, hipMemcpyDeviceToDevice, s));
@@ -698,6 +811,7 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     TRY(ready(m, B, true));
     ARG_CHECK(images && labels && loss, "forward_backward: null argument");
     hipStream_t s = (hipStream_t)stream;
+    if (m->cocoop) return cocoop_forward_backward(m, images, labels, B, grad_scale, loss, logits, s);
     const mudpt_config& c = m->cfg;
     const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, C = c.n_cls;
     const int Lv = m->vis.L, Lt = m->txt.L;

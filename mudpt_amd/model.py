@@ -57,7 +57,7 @@ class _Holder(nn.Module):
 class CustomCLIP(nn.Module):
     def __init__(self, shape: ModelShape, clip_state: Dict[str, torch.Tensor], tokenized_prompts: torch.Tensor,
                  ctx_token_ids: Optional[Sequence[int]] = None, max_batch: int = 256, dtype: str = "bf16",
-                 device: str = "cuda:0", seed: Optional[int] = None):
+                 device: str = "cuda:0", seed: Optional[int] = None, variant: str = "mudpt"):
         super().__init__()
         if not torch.cuda.is_available():
             raise capi.MudptError("mudpt_amd needs an MI355X (HIP device); there is no CPU path in the product")
@@ -68,9 +68,13 @@ class CustomCLIP(nn.Module):
         self.n_cls = int(tokenized_prompts.shape[0])
         self.max_batch = int(max_batch)
         self.tokenized_prompts = tokenized_prompts.clone()
+        # "cocoop": the same library runs trainers/cocoop.py's CustomCLIP (vanilla vision tower, meta_net, one text-tower pass
+        # per (image, class) pair); the module then owns ctx + meta_net under the reference's names (prompt_learner.*)
+        self.variant = variant
         cfg = capi.Config(shape.image_size, shape.patch, shape.v_width, shape.v_layers, shape.v_heads, shape.t_width,
                           shape.t_layers, shape.t_heads, shape.ctx_len, shape.embed_dim, shape.n_ctx, shape.depth,
-                          self.n_cls, self.max_batch, {"bf16": capi.BF16, "fp16": capi.F16}[dtype])
+                          self.n_cls, self.max_batch, {"bf16": capi.BF16, "fp16": capi.F16}[dtype],
+                          {"mudpt": capi.VARIANT_MUDPT, "cocoop": capi.VARIANT_COCOOP}[variant])
         torch.cuda.set_device(self.device)
         h = C.c_void_p()
         capi.check(self.lib.mudpt_create(C.byref(cfg), C.byref(h)), "create")
@@ -92,11 +96,6 @@ class CustomCLIP(nn.Module):
         self.flat_params = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.flat_grads = torch.zeros(total, dtype=torch.float32, device=self.device)
         capi.check(self.lib.mudpt_bind_params(h, capi.ptr(self.flat_params), capi.ptr(self.flat_grads)), "bind_params")
-        self.mudpt_prompt_learner = _Holder()
-        self.mudpt_prompt_learner.embed_projection = _Holder()
-        self.mudpt_prompt_learner.deep_projections = _Holder()
-        self.image_encoder = _Holder()
-        self.image_encoder.visual_ctx_deep_projections = _Holder()
         self.param_names = []
         for i in range(self.lib.mudpt_param_count(h)):
             name, off, numel, ndim, shp = C.c_char_p(), C.c_size_t(), C.c_size_t(), C.c_int32(), (C.c_int64 * 3)()
@@ -107,7 +106,9 @@ class CustomCLIP(nn.Module):
             p.grad = self.flat_grads[off.value:off.value + numel.value].view_as(view)
             mod = self
             *path, leaf = key.split(".")
-            for part in path:
+            for part in path:  # namespace modules along the reference's dotted key
+                if not hasattr(mod, part):
+                    setattr(mod, part, _Holder())
                 mod = getattr(mod, part)
             mod.register_parameter(leaf, p)
             self.param_names.append(key)
@@ -128,7 +129,11 @@ class CustomCLIP(nn.Module):
                     v = 0.02 * torch.randn(p.shape, generator=g)  # nn.init.normal_(std=0.02)
                 p.copy_(v)
             if ctx_token_ids is not None:  # CTX_INIT words -> their token embeddings
-                sd["mudpt_prompt_learner.ctx"].copy_(emb_w[list(ctx_token_ids)])
+                sd[self.ctx_key].copy_(emb_w[list(ctx_token_ids)])
+
+    @property
+    def ctx_key(self) -> str:
+        return "mudpt_prompt_learner.ctx" if self.variant == "mudpt" else "prompt_learner.ctx"
 
     def set_params(self, tensors: Dict[str, torch.Tensor]):
         with torch.no_grad():
@@ -150,7 +155,7 @@ class CustomCLIP(nn.Module):
         # eval mode: the text features only depend on the parameters; recompute them only when the flat bucket's version
         # counter moved (the reference re-runs the text tower for every test batch)
         version = self.flat_params._version
-        reuse = (not self.training) and self._text_version == version
+        reuse = (not self.training) and self._text_version == version and self.variant == "mudpt"  # CoCoOp's text features depend on the image
         capi.check(self.lib.mudpt_forward_ex(self._h, capi.ptr(image), B, capi.ptr(logits), 1 if reuse else 0, self._stream()), "forward")
         self._text_version = version
         return logits

@@ -3,6 +3,7 @@
 Run in the build container only (needs /root/reference, which never travels to the GPU box):
 
     python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+    python tests/golden/gen_golden.py --cocoop-only   # only the CoCoOp fixtures (trainers/cocoop.py)
 
 What runs: ``clip.model.CLIP`` and ``trainers.mudpt.CustomCLIP`` imported unmodified from
 /root/reference; their parameters are overwritten with the seeded recipe of
@@ -175,8 +176,61 @@ def run(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, t
           f"{os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def run_cocoop(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, train_seed: int, image_seed: int):
+    """CoCoOp fixtures from the reference's own trainers/cocoop.py CustomCLIP over the vanilla CLIP (cfg=None, cocoop.py:38)."""
+    from oracle import cocoop_oracle as CO
+    clip, cm, _mudpt, CN = import_reference()
+    from trainers import cocoop
+    ycfg = CN(TRAINER=CN(NAME="CoCoOp", COCOOP=CN(N_CTX=cfg.n_ctx, CTX_INIT=ctx_init, PREC="fp32")),
+              INPUT=CN(SIZE=(cfg.image_size, cfg.image_size)))
+    ref_clip = cm.CLIP(cfg.embed_dim, cfg.image_size, cfg.v_layers, cfg.v_width, cfg.patch, cfg.ctx_len,
+                       cfg.vocab, cfg.t_width, cfg.t_heads, cfg.t_layers, None).float()
+    frozen = O.make_frozen_state(cfg, frozen_seed)
+    missing, unexpected = ref_clip.load_state_dict(frozen, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    model = cocoop.CustomCLIP(ycfg, CLASSNAMES, ref_clip)
+    tok = model.tokenized_prompts
+    ctx_ids = [int(v) for v in clip.tokenize(ctx_init)[0, 1:1 + cfg.n_ctx]]
+    params = CO.make_trainable_state(cfg, train_seed, frozen, ctx_ids)
+    ref_params = dict(model.named_parameters())
+    assert torch.equal(ref_params["prompt_learner.ctx"].detach(), params["prompt_learner.ctx"])  # the reference's own CTX_INIT rule
+    with torch.no_grad():
+        for k in CO.TRAINABLE_ORDER:
+            ref_params[k].copy_(params[k])
+    for k, p in model.named_parameters():  # freeze rule, trainers/cocoop.py:222-226
+        p.requires_grad_("prompt_learner" in k)
+    assert sorted(k for k, p in model.named_parameters() if p.requires_grad) == sorted(CO.TRAINABLE_ORDER)
+    images = seeded_images(cfg, batch, image_seed)
+    labels = torch.arange(batch) * 3 % len(CLASSNAMES)
+    model.eval()
+    with torch.no_grad():
+        logits = model(images)          # eval mode returns logits (cocoop.py:198)
+    model.train()
+    loss = model(images, labels)        # training mode returns F.cross_entropy(logits, label) (cocoop.py:196-197)
+    loss.backward()
+    out = {
+        "config": np.array(repr(cfg.asdict())), "classnames": np.array(CLASSNAMES), "ctx_init": np.array(ctx_init),
+        "seeds": np.array([frozen_seed, train_seed, image_seed], dtype=np.int64),
+        "tokenized_prompts": tok.numpy().astype(np.int32), "ctx_token_ids": np.array(ctx_ids, dtype=np.int32),
+        "labels": labels.numpy().astype(np.int64),
+        "images_checksum": np.array([images.double().sum().item(), images.double().abs().sum().item()]),
+        "logits": logits.numpy(), "loss": np.array(loss.item(), dtype=np.float64),
+    }
+    for k in CO.TRAINABLE_ORDER:
+        out["grad." + k] = ref_params[k].grad.detach().numpy()
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: loss {loss.item():.6f}, logits[0,:3] {logits[0, :3].tolist()}, {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--cocoop-only" in sys.argv:
+        run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
+        run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)
+        sys.exit(0)
     run(O.TINY, "mudpt_tiny", "a photo", batch=3, frozen_seed=11, train_seed=12, image_seed=13, sample_big=False)
     run(O.VIT_B16, "mudpt_vitb16_b4", "a photo of a", batch=4, frozen_seed=0, train_seed=1, image_seed=1234,
         sample_big=True)
+    run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
+    run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)

@@ -24,7 +24,7 @@ def test_header_functions_are_exported_and_bound(lib):
 
 
 def test_abi_version(lib):
-    assert lib.mudpt_abi_version() == 1
+    assert lib.mudpt_abi_version() == capi.ABI_VERSION
 
 
 def test_padded_len_is_host_only(lib):

@@ -1,0 +1,89 @@
+"""GPU parity of the CoCoOp path (BASELINE configs[3]) through the C ABI: the HIP library with
+``variant = "cocoop"`` against the golden vectors of the reference's own ``trainers/cocoop.py`` and the CPU oracle."""
+import pytest
+import torch
+
+from oracle import cocoop_oracle as CO
+from oracle import mudpt_oracle as O
+from tests.helpers import GoldenCase
+
+pytestmark = pytest.mark.gpu
+
+# Same error model as tests/test_model_gpu.py (11-bit / 8-bit operands, fp32 accumulation); logit scale 14.29.
+LOGIT_RMS = {"fp16": 1e-3, "bf16": 1.6e-2}
+LOGIT_ATOL = {"fp16": 2e-3, "bf16": 3.2e-2}
+# Gradients, relative to each tensor's RMS.  ctx behaves like MuDPT's prompts.  meta_net's gradients come from d bias_i = sum over the
+# C class prompts (and n_ctx rows) of the text-input gradient, and sum_c dlogits[i, c] = 0: the per-class terms nearly cancel, so
+# the T-precision rounding of each term is amplified relative to the surviving signal.  Bounds: RMS error / max error.
+GRAD_RMS = {"fp16": 2e-2, "bf16": 1.5e-1}
+GRAD_MAX = {"fp16": 8e-2, "bf16": 1.2}  # bf16 (8-bit significand): single elements of the cancelling sums are only sanity-bounded
+
+
+def build(cfg, frozen, tokens, params, dtype, max_batch):
+    from mudpt_amd.model import CustomCLIP, ModelShape
+    shape = ModelShape(cfg.image_size, cfg.patch, cfg.v_width, cfg.v_layers, cfg.v_heads, cfg.t_width, cfg.t_layers, cfg.t_heads,
+                       cfg.ctx_len, cfg.embed_dim, cfg.n_ctx, 1)
+    m = CustomCLIP(shape, frozen, tokens, max_batch=max_batch, dtype=dtype, variant="cocoop")
+    assert m.param_names == CO.TRAINABLE_ORDER  # the reference's prompt_learner.* names, flat-bucket order
+    m.set_params(params)
+    return m
+
+
+@pytest.fixture(scope="module", params=["cocoop_tiny", "cocoop_vitb16_b2"])
+def case(request):
+    return GoldenCase(request.param)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_logits_loss_grads_match_reference(case, dtype):
+    m = build(case.cfg, case.frozen, case.tokens, case.params, dtype, len(case.labels))
+    m.eval()
+    logits = m(case.images).cpu()  # eval mode: logits (trainers/cocoop.py:198)
+    err, rms = (logits - case.logits).abs().max().item(), (logits - case.logits).pow(2).mean().sqrt().item()
+    print(f"{dtype}: |logit - reference| max {err:.3e} rms {rms:.3e}")
+    assert rms <= LOGIT_RMS[dtype] and err <= LOGIT_ATOL[dtype]
+    m.train()
+    loss, logits2 = m.forward_backward(case.images, case.labels, return_logits=True)  # training mode: CE inside forward (:196-197)
+    torch.cuda.synchronize()
+    assert torch.equal(logits2.cpu(), logits)  # same kernels, same order: bitwise
+    assert abs(loss.item() - case.loss) <= LOGIT_ATOL[dtype]
+    got = {k: v.detach().cpu() for k, v in m.grads().items()}
+    bad = []
+    for k in CO.TRAINABLE_ORDER:
+        r = case.grad(k)
+        rms_g = r.pow(2).mean().sqrt().item()
+        e, er = (got[k] - r).abs().max().item(), (got[k] - r).pow(2).mean().sqrt().item()
+        print(f"{dtype} {k}: rms {rms_g:.3e} rms err {er / rms_g:.3e} max err {e / rms_g:.3e} (relative to rms)")
+        if er > GRAD_RMS[dtype] * rms_g + 1e-9 or e > GRAD_MAX[dtype] * rms_g + 1e-9:
+            bad.append(k)
+    m.close()
+    assert not bad, bad
+
+
+def test_larger_batch_against_oracle_and_sgd():
+    """B = 6 images x 11 classes = 66 text sequences of the tiny shape, smaller batch than max_batch, then two SGD steps
+    (torch.optim.SGD semantics, as Dassl's build_optimizer) tracked against the oracle."""
+    cfg = O.TINY
+    frozen = O.make_frozen_state(cfg, 31)
+    tok = O.synthetic_tokens(cfg, 11).long()
+    params = CO.make_trainable_state(cfg, 32)
+    g = torch.Generator().manual_seed(33)
+    images, labels = torch.randn(6, 3, cfg.image_size, cfg.image_size, generator=g), torch.randint(0, 11, (6,), generator=g)
+    emb, eot = frozen["token_embedding.weight"][tok], tok.argmax(-1)
+    m = build(cfg, frozen, tok, params, "fp16", max_batch=8)
+    p, bufs = {k: v.clone() for k, v in params.items()}, {k: None for k in params}
+    for step in range(2):
+        loss, logits = m.forward_backward(images, labels, return_logits=True)
+        ref_loss, ref_logits, ref = CO.forward_backward(cfg, frozen, p, emb, eot, images, labels)
+        assert (logits.cpu() - ref_logits).abs().max().item() <= 3e-3  # 66 logits of random (untrained) prompts; measured 2.2e-3
+        assert abs(loss.item() - ref_loss.item()) <= 2e-3
+        for k in CO.TRAINABLE_ORDER:
+            r = ref[k]
+            assert (m.grads()[k].cpu() - r).pow(2).mean().sqrt().item() <= 2e-2 * r.pow(2).mean().sqrt().item() + 1e-9, (step, k)
+        m.sgd_step(0.002)
+        for k in CO.TRAINABLE_ORDER:
+            p[k], bufs[k] = O.sgd_step(p[k], ref[k], bufs[k], 0.002)
+    torch.cuda.synchronize()
+    for k, v in m.named_parameters():
+        assert (v.detach().cpu() - p[k]).abs().max().item() <= 1e-4, k
+    m.close()

@@ -67,3 +67,20 @@ def test_flat_bucket_roundtrip():
     for k in O.TRAINABLE_ORDER:
         assert torch.equal(p[k], q[k])
     assert O.flatten(O.make_trainable_state(O.VIT_B16, 1)).numel() == 1243136
+
+
+@pytest.mark.parametrize("name", ["cocoop_tiny", "cocoop_vitb16_b2"])
+def test_cocoop_forward_backward_matches_reference(name):
+    """The CoCoOp restatement (oracle/cocoop_oracle.py) against the reference's trainers/cocoop.py CustomCLIP: eval-mode
+    logits, training-mode loss (cross-entropy inside forward) and the gradients of ctx and meta_net."""
+    from oracle import cocoop_oracle as CO
+    case = GoldenCase(name)
+    case.check_recipe()
+    loss, logits, grads = CO.forward_backward(case.cfg, case.frozen, case.params, case.class_embedding, case.eot, case.images, case.labels)
+    torch.testing.assert_close(logits, case.logits, atol=2e-5, rtol=1e-5)
+    assert abs(loss.item() - case.loss) < 1e-5
+    for k in CO.TRAINABLE_ORDER:
+        ref = case.grad(k)
+        scale = ref.pow(2).mean().sqrt().item()
+        torch.testing.assert_close(grads[k], ref, atol=1e-3 * scale + 1e-9, rtol=1e-4)
+    assert CO.flatten(case.params).numel() == sum(int(np.prod(s)) for s in CO.trainable_shapes(case.cfg).values())
