@@ -1,0 +1,106 @@
+"""Drop-in ``CoCoOp`` trainer plugin: the reference's ``trainers/cocoop.py:201-307`` surface over libmudpt_hip.so
+(BASELINE configs[3]).
+
+Same class name, registry name, hooks and error behaviour: ``check_cfg`` (:203), ``build_model`` (:206), ``forward_backward``
+(:246), ``parse_batch_train`` (:278), inherited ``model_inference`` (``self.model(input)`` in eval mode returns logits, :198) and
+``load_model`` (:285).  As in the reference only the ``prompt_learner`` sub-module is given to the optimizer and registered
+(:237-240), so checkpoints hold ``ctx`` and ``meta_net.*`` under the same keys.  The per-image text-encoder loop of
+``CustomCLIP.forward`` (:187-194) is one batched pass over all (image, class) prompts inside the library.
+"""
+from __future__ import annotations
+
+import os.path as osp
+
+from . import parallel, synth
+from .model import CustomCLIP, ModelShape
+from .trainer import (PREC_TO_DTYPE, TRAINER_REGISTRY, TrainerX, build_lr_scheduler, build_optimizer, load_checkpoint,
+                      load_clip_state_dict, tokenize_prompts)
+
+
+@TRAINER_REGISTRY.register()
+class CoCoOp(TrainerX):
+    def check_cfg(self, cfg):
+        assert cfg.TRAINER.COCOOP.PREC in ["fp16", "fp32", "amp"]  # trainers/cocoop.py:204
+
+    def build_model(self):
+        cfg = self.cfg
+        classnames = self.dm.dataset.classnames
+        cc = cfg.TRAINER.COCOOP
+        print(f"Loading CLIP (backbone: {cfg.MODEL.BACKBONE.NAME})")
+        state = load_clip_state_dict(cfg)
+        n_ctx = cc.N_CTX
+        ctx_init = cc.CTX_INIT
+        near = cfg.MODEL.BACKBONE.PATH or None
+        if ctx_init:  # trainers/cocoop.py:79-87: n_ctx follows the init words
+            ctx_init = ctx_init.replace("_", " ")
+            n_ctx = len(ctx_init.split(" "))
+        if state is None:
+            shape = ModelShape(n_ctx=n_ctx, depth=1)
+            state = synth.random_clip_state(shape, cfg.MODEL.BACKBONE.SYNTHETIC_SEED)
+        else:
+            shape = ModelShape.from_state_dict(state, n_ctx, 1)
+        cfg_imsize = cfg.INPUT.SIZE[0]
+        assert cfg_imsize == shape.image_size, f"cfg_imsize ({cfg_imsize}) must equal to clip_imsize ({shape.image_size})"  # :77
+        if ctx_init:
+            ctx_ids = [int(v) for v in tokenize_prompts([ctx_init], shape.ctx_len, near=near)[0, 1:1 + n_ctx]] \
+                if ctx_init != "a photo of a" else synth.CTX_INIT_TOKENS[:n_ctx]
+            prompt_prefix = ctx_init
+        else:
+            ctx_ids, prompt_prefix = None, " ".join(["X"] * n_ctx)  # random N(0, 0.02^2) context (:90-92)
+        print(f'Initial context: "{prompt_prefix}"')
+        print(f"Number of context words (tokens): {n_ctx}")
+        prompts = [prompt_prefix + " " + name.replace("_", " ") + "." for name in classnames]  # :110-112
+        tokenized = tokenize_prompts(prompts, shape.ctx_len, near=near)
+
+        print("Building custom CLIP")
+        rank, world, local = parallel.env_rank()
+        max_batch = max(cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.DATALOADER.TEST.BATCH_SIZE)
+        self.model = CustomCLIP(shape, state, tokenized, ctx_token_ids=ctx_ids, max_batch=max_batch,
+                                dtype=PREC_TO_DTYPE[cc.PREC], device=f"cuda:{local}", seed=cfg.SEED, variant="cocoop")
+        print("Turning off gradients in both the image and the text encoder")  # structural: the module owns the 5 trainables only
+        print(f"Parameters to be updated: {set(self.model.param_names)}")
+        # NOTE: only give prompt_learner to the optimizer (:237)
+        self.optim = build_optimizer(self.model.prompt_learner, cfg.OPTIM)
+        self.sched = build_lr_scheduler(self.optim, cfg.OPTIM)
+        self.register_model("prompt_learner", self.model.prompt_learner, self.optim, self.sched)
+        self.scaler = None  # loss scaling lives inside the library
+        if parallel.world_size() > 1:  # the reference's nn.DataParallel (:244-247) becomes one process per GPU
+            parallel.broadcast_params(self.model.flat_params)
+
+    def forward_backward(self, batch):
+        image, label = self.parse_batch_train(batch)
+        # loss = model(image, label) (cross-entropy inside forward, :196-197) + backward in one library call
+        loss = self.model.forward_backward(image, label, grad_scale=parallel.grad_scale())
+        parallel.allreduce_grads(self.model.flat_grads)
+        self.optim.step()
+        loss_summary = {"loss": loss.item()}
+        if (self.batch_idx + 1) == self.num_batches:
+            self.update_lr()
+        return loss_summary
+
+    def parse_batch_train(self, batch):
+        input = batch["img"]
+        label = batch["label"]
+        input = input.to(self.device)
+        label = label.to(self.device)
+        return input, label
+
+    def load_model(self, directory, epoch=None):
+        if not directory:
+            print("Note that load_model() is skipped as no Pretrained model is given")
+            return
+        names = self.get_model_names()
+        model_file = "model-best.pth.tar"  # by default, the best model is loaded
+        if epoch is not None:
+            model_file = "model.pth.tar-" + str(epoch)
+        for name in names:
+            model_path = osp.join(directory, name, model_file)
+            if not osp.exists(model_path):
+                raise FileNotFoundError('Model not found at "{}"'.format(model_path))
+            checkpoint = load_checkpoint(model_path)
+            state_dict = checkpoint["state_dict"]
+            epoch = checkpoint["epoch"]
+            for k in ("token_prefix", "token_suffix"):  # ignore fixed token vectors (:303-307)
+                state_dict.pop(k, None)
+            print("Loading weights to {} " 'from "{}" (epoch = {})'.format(name, model_path, epoch))
+            self._models[name].load_state_dict(state_dict, strict=False)

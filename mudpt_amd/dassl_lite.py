@@ -41,7 +41,8 @@ def default_cfg() -> CfgNode:
         OPTIM=C(NAME="sgd", LR=0.0025, MAX_EPOCH=10, LR_SCHEDULER="cosine", WARMUP_EPOCH=1, WARMUP_TYPE="constant",
                 WARMUP_CONS_LR=1e-5, MOMENTUM=0.9, WEIGHT_DECAY=5e-4, SGD_DAMPNING=0.0, SGD_NESTEROV=False),
         TRAIN=C(PRINT_FREQ=5),
-        TRAINER=C(NAME="MuDPT", MUDPT=C(N_CTX=2, CTX_INIT="a photo of a", DEEP_PROMPT_DEPTH=8, PREC="fp16")),
+        TRAINER=C(NAME="MuDPT", MUDPT=C(N_CTX=2, CTX_INIT="a photo of a", DEEP_PROMPT_DEPTH=8, PREC="fp16"),
+                  COCOOP=C(N_CTX=4, CTX_INIT="a photo of a", PREC="fp16")),  # train.py:92-95 + configs/trainers/CoCoOp/*.yaml
     )
 
 

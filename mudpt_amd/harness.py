@@ -9,11 +9,12 @@ import argparse
 
 import torch
 
-from . import dassl_lite, parallel, trainer  # noqa: F401  (importing trainer registers MuDPT)
+from . import cocoop, dassl_lite, parallel, trainer  # noqa: F401  (importing trainer / cocoop registers MuDPT / CoCoOp)
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--trainer", default="MuDPT", choices=["MuDPT", "CoCoOp"])
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--classes", type=int, default=11)
@@ -36,11 +37,13 @@ def main(argv=None):
     cfg.DATALOADER.TEST.BATCH_SIZE = max(a.batch, 8)
     cfg.DATASET.NUM_CLASSES, cfg.DATASET.NUM_TRAIN, cfg.DATASET.NUM_TEST = a.classes, a.train_images, 16
     cfg.MODEL.BACKBONE.PATH = a.backbone_path
+    cfg.TRAINER.NAME = a.trainer
     cfg.TRAINER.MUDPT.N_CTX, cfg.TRAINER.MUDPT.DEEP_PROMPT_DEPTH, cfg.TRAINER.MUDPT.PREC = a.n_ctx, a.depth, a.prec
+    cfg.TRAINER.COCOOP.PREC = a.prec
     torch.manual_seed(cfg.SEED)
-    t = trainer.TRAINER_REGISTRY.get("MuDPT")(cfg) if not trainer.HAVE_DASSL else None
+    t = trainer.TRAINER_REGISTRY.get(a.trainer)(cfg) if not trainer.HAVE_DASSL else None
     if t is None:
-        raise SystemExit("Dassl is installed: use the reference's train.py --trainer MuDPT (see INTEGRATION.md)")
+        raise SystemExit("Dassl is installed: use the reference's train.py --trainer MuDPT / CoCoOp (see INTEGRATION.md)")
     if a.eval_only:
         t.load_model(a.model_dir, epoch=a.load_epoch)
         return t.test()

@@ -46,20 +46,22 @@ def load_clip_state_dict(cfg):
     return None
 
 
-def tokenize_prompts(prompts, ctx_len=77):
-    """clip.tokenize (clip/clip.py:199-239) when the reference's ``clip`` package is importable (drop-in use inside
-    the reference checkout); otherwise the recorded ids of the benchmark prompts."""
+def tokenize_prompts(prompts, ctx_len=77, near=None):
+    """clip.tokenize (clip/clip.py:199-239) by the native BPE tokenizer (mudpt_amd/tokenizer.py); the merge table is looked for
+    at $MUDPT_BPE_VOCAB, next to the checkpoint (``near``) and in an importable clip package.  Without a merge table only the
+    benchmark prompts (recorded ids) can be served."""
+    from . import tokenizer
     try:
-        import clip  # the reference's package, present when this plugin is dropped into its checkout
-        return torch.cat([clip.tokenize(p) for p in prompts]).int()
-    except ImportError:
+        return tokenizer.tokenize(list(prompts), ctx_len, near=near)
+    except RuntimeError as no_vocab:
+        if "merge table" not in str(no_vocab):
+            raise
         table = {f"a photo of a {n}.": i for i, n in enumerate(synth.BENCH_CLASSNAMES)}
         tok = synth.bench_tokenized_prompts(ctx_len)
         try:
             return torch.stack([tok[table[p]] for p in prompts])
         except KeyError as e:
-            raise RuntimeError(f"no BPE tokenizer available for prompt {e}; run inside the reference checkout (clip/) "
-                               "or use the benchmark class names") from None
+            raise RuntimeError(f"no BPE merge table available for prompt {e}: {no_vocab}") from None
 
 
 @TRAINER_REGISTRY.register()
@@ -88,7 +90,7 @@ class MuDPT(TrainerX):
         if ctx_init:
             ctx_init = ctx_init.replace("_", " ")
             prompt_prefix = " ".join(ctx_init.split()[:mc.N_CTX])
-            ctx_ids = [int(v) for v in tokenize_prompts([ctx_init], shape.ctx_len)[0, 1:1 + mc.N_CTX]] \
+            ctx_ids = [int(v) for v in tokenize_prompts([ctx_init], shape.ctx_len, near=cfg.MODEL.BACKBONE.PATH or None)[0, 1:1 + mc.N_CTX]] \
                 if ctx_init != "a photo of a" else synth.CTX_INIT_TOKENS[:mc.N_CTX]
         else:
             print("Initializing A Generic Context")
@@ -97,7 +99,7 @@ class MuDPT(TrainerX):
         print(f"Number of context words (tokens): {mc.N_CTX}")
         print(f"Depth of deep prompt: {mc.DEEP_PROMPT_DEPTH}")
         prompts = [prompt_prefix + " " + name.replace("_", " ") + "." for name in classnames]
-        tokenized = tokenize_prompts(prompts, shape.ctx_len)
+        tokenized = tokenize_prompts(prompts, shape.ctx_len, near=cfg.MODEL.BACKBONE.PATH or None)
 
         print("Building custom CLIP")
         rank, world, local = parallel.env_rank()

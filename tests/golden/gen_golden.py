@@ -223,8 +223,37 @@ def run_cocoop(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed:
     print(f"wrote {path}: loss {loss.item():.6f}, logits[0,:3] {logits[0, :3].tolist()}, {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+TOKENIZER_STRINGS = [
+    "a photo of a face.", "a photo of a binocular.", "X X X X water lily.", "a photo of a Boeing 737-200, a type of aircraft.",
+    "a centered satellite photo of annual crop land.", "a photo of a 2012 Audi S5 Coupe.", "crème brûlée", "Dr. Strange's cat",
+    "it's  a   DOG!!", "they're we've I'm you'll he'd can't", "hello &amp; goodbye &amp;amp; more", "1999 12345 3.14", "snake_case_name",
+    "UPPER lower MiXeD", "a photo of a person doing Apply Eye Makeup.", "a photo of a cheese plate, a type of food.", "ñandú über naïve",
+    "日本語 のテキスト", "emoji 😀 test", "tab\tand\nnewline", "  leading and trailing  ", "a-b-c d/e/f (g) [h] {i}", "<|startoftext|> inner <|endoftext|>",
+    "a photo of a wandering albatross, a type of bird.", "itap of a motorbike.", "a bad photo of the accordion.", "!!!", "a", "",
+    "a photo of a " + "very " * 40 + "long name.",
+]
+
+
+def run_tokenizer():
+    """Token ids of the reference's own tokenizer (clip/simple_tokenizer.py via clip.tokenize) for a list of strings."""
+    import json
+    clip, _cm, _mudpt, _CN = import_reference()
+    cases = []
+    for t in TOKENIZER_STRINGS:
+        ids = [int(v) for v in clip.tokenize(t, truncate=True)[0]]
+        n = len(ids) - ids[::-1].index(49407)  # through the LAST end-of-text id (a string may contain the marker itself)
+        cases.append({"text": t, "ids": ids[:n]})
+    path = os.path.join(ROOT, "tests", "golden", "tokenizer_cases.json")
+    with open(path, "w") as f:
+        json.dump({"context_length": 77, "truncate": True, "cases": cases}, f, ensure_ascii=False, indent=0)
+    print(f"wrote {path}: {len(cases)} strings")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--tokenizer-only" in sys.argv:
+        run_tokenizer()
+        sys.exit(0)
     if "--cocoop-only" in sys.argv:
         run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
         run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)
@@ -234,3 +263,4 @@ if __name__ == "__main__":
         sample_big=True)
     run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
     run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)
+    run_tokenizer()

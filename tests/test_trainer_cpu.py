@@ -13,6 +13,23 @@ def test_plugin_is_registered_under_the_reference_name():
         assert callable(getattr(trainer.MuDPT, hook))
 
 
+def test_cocoop_plugin_is_registered_under_the_reference_name():
+    from mudpt_amd import cocoop
+    assert "CoCoOp" in trainer.TRAINER_REGISTRY.registered_names()  # train.py --trainer CoCoOp
+    for hook in ("check_cfg", "build_model", "forward_backward", "parse_batch_train", "load_model", "model_inference"):
+        assert callable(getattr(cocoop.CoCoOp, hook))
+    cfg = dassl_lite.default_cfg()
+    t = object.__new__(cocoop.CoCoOp)
+    t.check_cfg(cfg)
+    cfg.TRAINER.COCOOP.PREC = "int8"
+    with pytest.raises(AssertionError):  # trainers/cocoop.py:204
+        t.check_cfg(cfg)
+    t._models = {"prompt_learner": torch.nn.Linear(2, 2)}
+    assert t.load_model("") is None
+    with pytest.raises(FileNotFoundError):  # trainers/cocoop.py:296-297
+        t.load_model("/nonexistent", epoch=3)
+
+
 def test_check_cfg_matches_reference_assert():
     cfg = dassl_lite.default_cfg()
     t = object.__new__(trainer.MuDPT)

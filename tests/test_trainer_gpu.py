@@ -36,3 +36,34 @@ def test_trainer_steps_and_checkpoint_roundtrip(tmp_path):
     assert torch.allclose(t.model_inference(batch["img"].cuda()), logits, atol=1e-5)
     acc = t.test()
     assert 0.0 <= acc <= 100.0
+
+
+def test_cocoop_trainer_steps_and_checkpoint_roundtrip(tmp_path):
+    """trainers/cocoop.py's surface: only prompt_learner is registered / optimised; checkpoints hold ctx + meta_net.*."""
+    from mudpt_amd import cocoop, dassl_lite  # noqa: F401  (registers CoCoOp)
+    cfg = dassl_lite.default_cfg()
+    cfg.TRAINER.NAME = "CoCoOp"
+    cfg.OUTPUT_DIR = str(tmp_path)
+    cfg.OPTIM.MAX_EPOCH, cfg.OPTIM.WARMUP_EPOCH, cfg.OPTIM.LR = 2, 0, 0.02
+    cfg.DATASET.NUM_TRAIN, cfg.DATASET.NUM_TEST = 8, 8
+    cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.DATALOADER.TEST.BATCH_SIZE = 2, 4
+    t = dassl_lite.build_trainer(cfg)
+    assert type(t).__name__ == "CoCoOp" and t.get_model_names() == ["prompt_learner"]
+    assert sorted(t.model.prompt_learner.state_dict()) == ["ctx", "meta_net.linear1.bias", "meta_net.linear1.weight",
+                                                           "meta_net.linear2.bias", "meta_net.linear2.weight"]
+    assert sum(p.numel() for p in t.model.parameters()) == 4 * 512 + 32 * 512 + 32 + 512 * 32 + 512
+    batch = t.train_loader_x[0]
+    t.batch_idx, t.num_batches = 0, 99
+    losses = [t.forward_backward(batch)["loss"] for _ in range(6)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    logits = t.model_inference(batch["img"].cuda())
+    assert logits.shape == (2, 11) and torch.isfinite(logits).all()
+    t.save_model(1, str(tmp_path))
+    before = {k: v.clone() for k, v in t.model.state_dict().items()}
+    with torch.no_grad():
+        for p in t.model.parameters():
+            p.add_(1.0)
+    t.load_model(str(tmp_path), epoch=2)
+    for k, v in t.model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert torch.allclose(t.model_inference(batch["img"].cuda()), logits, atol=1e-5)
