@@ -6,7 +6,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libmudpt_hip.so")
+LIB_PATH = os.environ.get("MUDPT_LIB") or os.path.join(HERE, "lib", "libmudpt_hip.so")  # MUDPT_LIB: A/B runs of two builds on one box
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "mudpt.h")
 
 BF16, F16 = 0, 1

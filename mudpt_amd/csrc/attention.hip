@@ -214,13 +214,17 @@ __global__ __launch_bounds__(NC * 64) void attn_fwd_kernel(AttnArgs p) {
     const size_t ld = (size_t)3 * HD;
     const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
 
+    // This wave's (at most two: L <= 32 NC) query blocks.  Their Q fragments are requested BEFORE the K / V staging so the
+    // HBM round trip overlaps it (fetched inside the block loop, every block exposed one more memory latency per wave).
+    const int nqb = (L + 15) >> 4, qbA = wave, qbB = wave + NC;
+    const typename T::vec8 qa0 = A::grow(base, ld, qbA * 16 + c, L, 0, lane), qa1 = A::grow(base, ld, qbA * 16 + c, L, 1, lane);
+    const typename T::vec8 qb0 = A::grow(base, ld, qbB * 16 + c, L, 0, lane), qb1 = A::grow(base, ld, qbB * 16 + c, L, 1, lane);
     A::template stage2<4>(Ks, base + HD, ld, Vs, base + 2 * HD, ld, L, tid, NT);
     for (int i = tid; i < Lp; i += NT) kmask[i] = i < L ? 0.f : -INFINITY;
     __syncthreads();
 
-    const int nqb = (L + 15) >> 4;
-    for (int qb = wave; qb < nqb; qb += NC)
-        fwd_qblock<T, NC, CAUSAL>(p, Ks, Vs, kmask, pair, qb, A::grow(base, ld, qb * 16 + c, L, 0, lane), A::grow(base, ld, qb * 16 + c, L, 1, lane), lane);
+    if (qbA < nqb) fwd_qblock<T, NC, CAUSAL>(p, Ks, Vs, kmask, pair, qbA, qa0, qa1, lane);
+    if (qbB < nqb) fwd_qblock<T, NC, CAUSAL>(p, Ks, Vs, kmask, pair, qbB, qb0, qb1, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -246,16 +250,23 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
     const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
     const elem* Of = (const elem*)fwd_out + (size_t)b * L * HD + hd * 64;
 
+    struct Frags { vec8 q0, q1, g0, g1, o0, o1; };
+    auto fetch = [&](int qb) {
+        const int q = qb * 16 + c;
+        return Frags{A::grow(base, ld, q, L, 0, lane), A::grow(base, ld, q, L, 1, lane), A::grow(dO, HD, q, L, 0, lane),
+                     A::grow(dO, HD, q, L, 1, lane), A::grow(Of, HD, q, L, 0, lane), A::grow(Of, HD, q, L, 1, lane)};
+    };
+    // the first block's Q / dO / O fragments travel during the K / V staging, the second block's during the first block's compute
+    const int nqb = (L + 15) >> 4, qbA = wave, qbB = wave + NC;
+    const Frags fa = fetch(qbA);
     A::template stage2<4>(Ks, base + HD, ld, Vs, base + 2 * HD, ld, L, tid, NT);
     for (int i = tid; i < Lp; i += NT) kmask[i] = i < L ? 0.f : -INFINITY;
     __syncthreads();
+    const Frags fb = fetch(qbB);
 
-    const int nqb = (L + 15) >> 4;
-    for (int qb = wave; qb < nqb; qb += NC) {
+    auto block = [&](int qb, const Frags& f) {
         const int q = qb * 16 + c;
-        const vec8 q0 = A::grow(base, ld, q, L, 0, lane), q1 = A::grow(base, ld, q, L, 1, lane);
-        const vec8 g0 = A::grow(dO, HD, q, L, 0, lane), g1 = A::grow(dO, HD, q, L, 1, lane);
-        const vec8 o0 = A::grow(Of, HD, q, L, 0, lane), o1 = A::grow(Of, HD, q, L, 1, lane);
+        const vec8 q0 = f.q0, q1 = f.q1, g0 = f.g0, g1 = f.g1, o0 = f.o0, o1 = f.o1;
         float delta = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) delta += (float)g0[i] * (float)o0[i] + (float)g1[i] * (float)o1[i];
@@ -292,7 +303,9 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
             for (int dt = 0; dt < 4; ++dt) dQ[dt] = T::mfma16(A::cols(Ks, kc * 32, dt * 16, lane), db, dQ[dt]);
         }
         if (q < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + q) * ld + hd * 64, dQ, 0.125f, lane);
-    }
+    };
+    if (qbA < nqb) block(qbA, fa);
+    if (qbB < nqb) block(qbB, fb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -318,6 +331,15 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
     const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
     const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
 
+    // this wave's (at most two) key blocks: K / V fragments requested before the Q / dO staging
+    const int nkb = (L + 15) >> 4, kbA = wave, kbB = wave + NC;
+    struct Frags { vec8 k0, k1, v0, v1; };
+    auto fetch = [&](int kb) {
+        const int key = kb * 16 + c;
+        return Frags{A::grow(base + HD, ld, key, L, 0, lane), A::grow(base + HD, ld, key, L, 1, lane),
+                     A::grow(base + 2 * HD, ld, key, L, 0, lane), A::grow(base + 2 * HD, ld, key, L, 1, lane)};
+    };
+    const Frags fa = fetch(kbA), fb = fetch(kbB);
     A::template stage2<4>(Qs, base, ld, Gs, dO, (size_t)HD, L, tid, NT);
     for (int i = tid; i < Lp; i += NT) {
         const size_t stat = ((size_t)b * p.H + hd) * Lp + i;
@@ -326,11 +348,9 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
     }
     __syncthreads();
 
-    const int nkb = (L + 15) >> 4;
-    for (int kb = wave; kb < nkb; kb += NC) {
+    auto block = [&](int kb, const Frags& f) {
         const int key = kb * 16 + c;
-        const vec8 k0 = A::grow(base + HD, ld, key, L, 0, lane), k1 = A::grow(base + HD, ld, key, L, 1, lane);
-        const vec8 v0 = A::grow(base + 2 * HD, ld, key, L, 0, lane), v1 = A::grow(base + 2 * HD, ld, key, L, 1, lane);
+        const vec8 k0 = f.k0, k1 = f.k1, v0 = f.v0, v1 = f.v1;
         f32x4 dK[4], dV[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -368,7 +388,9 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
             A::store_t(ok, dK, 0.125f, lane);
             A::store_t(ok + HD, dV, 1.f, lane);
         }
-    }
+    };
+    if (kbA < nkb) block(kbA, fa);
+    if (kbB < nkb) block(kbB, fb);
 }
 
 // ------------------------------------------------------------------------------------------------
