@@ -11,7 +11,7 @@ from mudpt_amd import capi
 def main():
     lib = capi.load()
     P = lambda t: C.c_void_p(t.data_ptr())
-    for name, B, L, H, causal in (("vision", 256, 201, 12, 0), ("text", 11, 77, 8, 1), ("text1000", 1000, 77, 8, 1)):
+    for name, B, L, H, causal in (("vision", 256, 201, 12, 0), ("vision, head-contiguous (B*H seqs, H=1)", 3072, 201, 1, 0), ("text", 11, 77, 8, 1), ("text1000", 1000, 77, 8, 1)):
         Lp = lib.mudpt_attention_padded_len(L)
         qkv = torch.randn(B, L, 3 * H * 64, device="cuda").to(torch.bfloat16)
         dout = torch.randn(B, L, H * 64, device="cuda").to(torch.bfloat16)
