@@ -109,6 +109,22 @@ struct Attn {
         if (row < L) v = *(const vec8*)(src + (size_t)row * ld + ks * 32 + (lane >> 4) * 8);
         return v;
     }
+    // the same, plus the rounding remainder to a second row (the low half of a split operand)
+    __device__ static inline void store_t_split(elem* dst_row, elem* lo_row, const f32x4 (&x)[4], float scale, int lane) {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            vec4 v, l;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float f = x[dt][r] * scale;
+                v[r] = (elem)f;
+                l[r] = (elem)(f - (float)v[r]);
+            }
+            *(vec4*)(dst_row + 16 * dt + 4 * g) = v;
+            *(vec4*)(lo_row + 16 * dt + 4 * g) = l;
+        }
+    }
     // D^T tile set (4 tiles of 16 d x 16 rows) -> dst[row][16 dt + 4 g + r]
     __device__ static inline void store_t(elem* dst_row, const f32x4 (&x)[4], float scale, int lane) {
         const int g = lane >> 4;
@@ -191,7 +207,12 @@ __device__ inline void fwd_qblock(const AttnArgs& p, const typename T::elem* Ks,
             for (int dt = 0; dt < 4; ++dt) O[dt] = T::mfma16(A::cols(Vs, kc * 32, dt * 16, lane), pb, O[dt]);
         }
     const int b = pair / p.H, hd = pair - b * p.H;
-    if (q < L) A::store_t((elem*)p.out + ((size_t)b * L + q) * HD + hd * 64, O, 1.f / l, lane);
+    const size_t ldo = p.ld_out ? (size_t)p.ld_out : (size_t)HD;
+    if (q < L) {
+        const size_t off = ((size_t)b * L + q) * ldo + hd * 64;
+        if (p.out_lo) A::store_t_split((elem*)p.out + off, (elem*)p.out_lo + off, O, 1.f / l, lane);
+        else A::store_t((elem*)p.out + off, O, 1.f / l, lane);
+    }
     if (g == 0 && p.lse) p.lse[(size_t)pair * Lp + q] = q < L ? m * 0.125f + __logf(l) : 0.f;
 }
 
@@ -248,13 +269,14 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
     const size_t ld = (size_t)3 * HD;
     const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
     const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
-    const elem* Of = (const elem*)fwd_out + (size_t)b * L * HD + hd * 64;
+    const size_t ldof = p.ld_out ? (size_t)p.ld_out : (size_t)HD;  // the forward output may be the hi half of a [hi | lo] row
+    const elem* Of = (const elem*)fwd_out + (size_t)b * L * ldof + hd * 64;
 
     struct Frags { vec8 q0, q1, g0, g1, o0, o1; };
     auto fetch = [&](int qb) {
         const int q = qb * 16 + c;
         return Frags{A::grow(base, ld, q, L, 0, lane), A::grow(base, ld, q, L, 1, lane), A::grow(dO, HD, q, L, 0, lane),
-                     A::grow(dO, HD, q, L, 1, lane), A::grow(Of, HD, q, L, 0, lane), A::grow(Of, HD, q, L, 1, lane)};
+                     A::grow(dO, HD, q, L, 1, lane), A::grow(Of, ldof, q, L, 0, lane), A::grow(Of, ldof, q, L, 1, lane)};
     };
     // the first block's Q / dO / O fragments travel during the K / V staging, the second block's during the first block's compute
     const int nqb = (L + 15) >> 4, qbA = wave, qbB = wave + NC;

@@ -146,6 +146,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
                                       (elem)quick_gelu(v[3])};
                 *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = u;
                 *(typename T::vec4*)((elem*)p.out1 + orow * p.ldo1 + n) = g;
+                if (p.out1_lo) {  // split operand: the next GEMM contracts over [hi | lo] against [W | W]
+                    typename T::vec4 lo = {(elem)(quick_gelu(v[0]) - (float)g[0]), (elem)(quick_gelu(v[1]) - (float)g[1]),
+                                           (elem)(quick_gelu(v[2]) - (float)g[2]), (elem)(quick_gelu(v[3]) - (float)g[3])};
+                    *(typename T::vec4*)((elem*)p.out1_lo + orow * p.ldo1 + n) = lo;
+                }
             } else if constexpr (EPI == EPI_RESIDUAL) {
                 const f32x4 r4 = *(const f32x4*)((const float*)p.aux + orow * p.ldaux + n);
                 *(f32x4*)((float*)p.out0 + orow * p.ldo0 + n) = v + r4;
@@ -213,7 +218,7 @@ static int launch_t(int epi, const GemmArgs& a, hipStream_t s) {
 bool gemm_uses_pp(int epi, const GemmArgs& a) {
     const bool pp_epi = epi == EPI_STORE || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32;
     const int v = g_gemm_variant & 0xff;
-    return (v == 0 || v == 3) && pp_epi && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
+    return (v == 0 || v == 3) && pp_epi && !a.out1_lo && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
            (epi != EPI_GELU_BWD || a.ldaux % 8 == 0);
 }
 

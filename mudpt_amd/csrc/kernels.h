@@ -26,6 +26,7 @@ struct GemmArgs {
     const float* bias = nullptr;  // [N] or null
     void* out0 = nullptr; int ldo0 = 0;
     void* out1 = nullptr; int ldo1 = 0;
+    void* out1_lo = nullptr;       // EPI_GELU only: out1_lo (T) = gelu(u) - out1, the low half of a split operand (row stride ldo1)
     const void* aux = nullptr; int ldaux = 0;
     int flags = 0;                 // bit 0: no XCD remap of the block id (tuning)
     int patches = 0, seq_len = 0;  // EPI_PATCH: P, L
@@ -46,6 +47,7 @@ struct LnFwdArgs {
     const int* row_index = nullptr;            // optional gather of input rows
     const float* gamma = nullptr; const float* beta = nullptr;
     void* out = nullptr; int ldo = 0;          // T or fp32 (out_f32)
+    void* out_lo = nullptr;                    // optional (T only): y - out, the low half of a split operand (row stride ldo)
     float* mean = nullptr; float* rstd = nullptr;  // [rows] saved statistics (may be null)
     int rows = 0, d = 0; bool out_f32 = false;
     // Fused residual add + prompt splice (identity row map only): v = x[r] + add[r]; rows (r % ov_L) in
@@ -78,7 +80,9 @@ int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s);
 // ------------------------------------------------------------------------------------------------
 struct AttnArgs {
     const void* qkv = nullptr;  // T [B, L, 3*H*64]
-    void* out = nullptr;        // fwd: T [B, L, H*64]
+    void* out = nullptr;        // fwd: T [B, L, H*64] (row stride ld_out elements, 0 = H*64)
+    void* out_lo = nullptr;     // fwd, optional: out_lo = O - out, the low half of a split operand (same stride)
+    int ld_out = 0;
     float* lse = nullptr;       // [B, H, Lp] natural-log-sum-exp of the scaled scores (Lp = padded L)
     const void* dout = nullptr; // bwd: T [B, L, H*64]
     void* dqkv = nullptr;       // bwd: T [B, L, 3*H*64]

@@ -69,6 +69,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs p) {
             } else {
                 typename T::vec4 o = {(elem)y[0], (elem)y[1], (elem)y[2], (elem)y[3]};
                 ((typename T::vec4*)((elem*)p.out + (size_t)r * p.ldo))[i] = o;
+                if (p.out_lo) {
+                    typename T::vec4 lo = {(elem)(y[0] - (float)o[0]), (elem)(y[1] - (float)o[1]), (elem)(y[2] - (float)o[2]), (elem)(y[3] - (float)o[3])};
+                    ((typename T::vec4*)((elem*)p.out_lo + (size_t)r * p.ldo))[i] = lo;
+                }
             }
         }
     }

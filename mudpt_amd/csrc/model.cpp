@@ -55,6 +55,7 @@ struct DevBuf {
 struct BlockW {
     void *w_in = nullptr, *w_in_t = nullptr, *w_out = nullptr, *w_out_t = nullptr;
     void *w_fc = nullptr, *w_fc_t = nullptr, *w_proj = nullptr, *w_proj_t = nullptr;
+    void *w_in2 = nullptr, *w_out2 = nullptr, *w_fc2 = nullptr, *w_proj2 = nullptr;  // Tower::split: [W | W], rows of 2 x in
     float *b_in = nullptr, *b_out = nullptr, *b_fc = nullptr, *b_proj = nullptr;
     float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
 };
@@ -69,6 +70,11 @@ struct BlockAct {
 struct Tower {
     int d = 0, layers = 0, heads = 0, L = 0, max_seq = 0, Lp = 0;
     bool causal = false;
+    // Split operands (text tower in fp16 mode, the parity configuration): the forward GEMMs' A operands -- both LayerNorm
+    // outputs, the attention output and QuickGELU(u) -- are stored as [hi | lo] with lo = value - hi, and contracted against
+    // [W | W] (K doubled).  Weights are fp16-exact (CLIP checkpoints are fp16-stored), so this removes the 11-bit rounding of
+    // those four operands, which is 87 % of the text-feature error (measured: 6.3e-4 -> 3.1e-4 relative).
+    bool split = false;
     int prompt_row0 = 0;  // first prompt row inside a sequence (vision: L - n, text: 1)
     std::vector<BlockW> w;
     std::vector<BlockAct> a;  // layers entries; the last block's output exists on the tail rows only (xout_sel)
@@ -175,6 +181,7 @@ static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s) 
 }
 
 static bool g_lp_grad_default = true;
+static bool g_txt_split_default = true;  // fp16 mode: split operands in the text tower (Tower::split); mudpt_debug_set("txt_split")
 
 static const char* kParamNames[10] = {
     "mudpt_prompt_learner.ctx",
@@ -212,7 +219,9 @@ static int dev_alloc(mudpt_model* m, void** out, size_t bytes) {
         if (int _e = dev_alloc(m, (void**)&(ptr), (size_t)(bytes))) return _e; \
     } while (0)
 
-static int alloc_tower(mudpt_model* m, Tower& t, int d, int layers, int heads, int L, int max_seq, bool causal, int prompt_row0) {
+static int alloc_tower(mudpt_model* m, Tower& t, int d, int layers, int heads, int L, int max_seq, bool causal, int prompt_row0, bool split = false) {
+    t.split = split;
+    const size_t sp = split ? 2 : 1;
     t.d = d; t.layers = layers; t.heads = heads; t.L = L; t.max_seq = max_seq; t.causal = causal;
     t.prompt_row0 = prompt_row0;
     t.Lp = attn_padded_len(L);
@@ -225,22 +234,26 @@ static int alloc_tower(mudpt_model* m, Tower& t, int d, int layers, int heads, i
         ALLOC(w.w_out, (size_t)d * d * 2); ALLOC(w.w_out_t, (size_t)d * d * 2);
         ALLOC(w.w_fc, (size_t)4 * d * d * 2); ALLOC(w.w_fc_t, (size_t)4 * d * d * 2);
         ALLOC(w.w_proj, (size_t)4 * d * d * 2); ALLOC(w.w_proj_t, (size_t)4 * d * d * 2);
+        if (split) {
+            ALLOC(w.w_in2, (size_t)3 * d * 2 * d * 2); ALLOC(w.w_out2, (size_t)d * 2 * d * 2);
+            ALLOC(w.w_fc2, (size_t)4 * d * 2 * d * 2); ALLOC(w.w_proj2, (size_t)d * 8 * d * 2);
+        }
         ALLOC(w.b_in, 3 * d * 4); ALLOC(w.b_out, d * 4); ALLOC(w.b_fc, 4 * d * 4); ALLOC(w.b_proj, d * 4);
         ALLOC(w.ln1_g, d * 4); ALLOC(w.ln1_b, d * 4); ALLOC(w.ln2_g, d * 4); ALLOC(w.ln2_b, d * 4);
         BlockAct& a = t.a[i];
         ALLOC(a.x_in, M * d * 4); ALLOC(a.x_mid, M * d * 4);
         ALLOC(a.mean1, M * 4); ALLOC(a.rstd1, M * 4); ALLOC(a.mean2, M * 4); ALLOC(a.rstd2, M * 4);
-        ALLOC(a.qkv, M * 3 * d * 2); ALLOC(a.attn, M * d * 2); ALLOC(a.u, M * 4 * d * 2);
+        ALLOC(a.qkv, M * 3 * d * 2); ALLOC(a.attn, M * d * 2 * sp); ALLOC(a.u, M * 4 * d * 2);
         ALLOC(a.lse, (size_t)max_seq * heads * t.Lp * 4);
     }
-    ALLOC(t.h, M * d * 2); ALLOC(t.g, M * 4 * d * 2);
+    ALLOC(t.h, M * d * 2 * sp); ALLOC(t.g, M * 4 * d * 2 * sp);
     ALLOC(t.dx, M * d * 4); ALLOC(t.dx_lp, M * d * 2);
     ALLOC(t.dattn, M * d * 2); ALLOC(t.dqkv, M * 3 * d * 2);
     ALLOC(t.delta, (size_t)max_seq * heads * t.Lp * 4);
     ALLOC(t.upd, M * d * 4);
     const size_t S = (size_t)max_seq;
     ALLOC(t.xin_sel, S * d * 4); ALLOC(t.xmid_sel, S * d * 4); ALLOC(t.xout_sel, S * d * 4);
-    ALLOC(t.attn_sel, S * d * 2); ALLOC(t.h_sel, S * d * 2); ALLOC(t.u_sel, S * 4 * d * 2); ALLOC(t.g_sel, S * 4 * d * 2); ALLOC(t.dattn_sel, S * d * 2);
+    ALLOC(t.attn_sel, S * d * 2 * sp); ALLOC(t.h_sel, S * d * 2 * sp); ALLOC(t.u_sel, S * 4 * d * 2); ALLOC(t.g_sel, S * 4 * d * 2 * sp); ALLOC(t.dattn_sel, S * d * 2);
     ALLOC(t.dsel, S * d * 4); ALLOC(t.dsel_lp, S * d * 2);
     t.head_n = m->cfg.n_ctx;
     ALLOC(t.hd_dqkv, S * t.head_n * 3 * d * 2); ALLOC(t.hd_h, S * t.head_n * d * 2);
@@ -285,7 +298,7 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     const int TS = cocoop ? B * C : C;  // text sequences per step: one per (image, class) pair in CoCoOp (trainers/cocoop.py:187-194)
     auto fail = [&](int code) { mudpt_destroy(m); return code; };
     if (int r = alloc_tower(m, m->vis, dv, c->v_layers, c->v_heads, Lv, B, false, cocoop ? Lv : Lv - n)) return fail(r);
-    if (int r = alloc_tower(m, m->txt, dt, c->t_layers, c->t_heads, c->ctx_len, TS, true, 1)) return fail(r);
+    if (int r = alloc_tower(m, m->txt, dt, c->t_layers, c->t_heads, c->ctx_len, TS, true, 1, c->dtype == MUDPT_F16 && g_txt_split_default)) return fail(r);
     auto body = [&]() -> int {
         const int K0 = 3 * c->patch * c->patch;
         ALLOC(m->conv_w, (size_t)dv * K0 * 2);
@@ -388,6 +401,16 @@ static int upload_lp(int dtype, void* dst, void* dst_t, const float* src, size_t
     return MUDPT_OK;
 }
 
+// W [rows, cols] fp32 host -> T device [rows, 2 cols] = [W | W]: the B operand of a split-operand GEMM
+static int upload_lp_dup(int dtype, void* dst, const float* src, size_t rows, size_t cols) {
+    std::vector<uint16_t> tmp(rows * 2 * cols);
+    auto cv = [&](float f) { return dtype == DT_BF16 ? f32_to_bf16(f) : f32_to_f16(f); };
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < cols; ++c) tmp[r * 2 * cols + c] = tmp[r * 2 * cols + cols + c] = cv(src[r * cols + c]);
+    HIP_TRY(hipMemcpy(dst, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    return MUDPT_OK;
+}
+
 static int set_block_weight(mudpt_model* m, Tower& t, int layer, const std::string& name, const float* data, size_t numel) {
     ARG_CHECK(layer >= 0 && layer < t.layers, "set_weight: layer %d out of range", layer);
     BlockW& w = t.w[layer];
@@ -401,12 +424,13 @@ static int set_block_weight(mudpt_model* m, Tower& t, int layer, const std::stri
             ARG_CHECK(numel == f.sz, "set_weight: %s expects %zu elements, got %zu", f.n, f.sz, numel);
             return upload_f32(f.p, data, numel);
         }
-    struct LP { const char* n; void* p; void* pt; size_t rows, cols; };
-    const LP lps[] = {{"attn.in_proj_weight", w.w_in, w.w_in_t, 3 * d, d}, {"attn.out_proj.weight", w.w_out, w.w_out_t, d, d},
-                      {"mlp.c_fc.weight", w.w_fc, w.w_fc_t, 4 * d, d}, {"mlp.c_proj.weight", w.w_proj, w.w_proj_t, d, 4 * d}};
+    struct LP { const char* n; void* p; void* pt; void* p2; size_t rows, cols; };
+    const LP lps[] = {{"attn.in_proj_weight", w.w_in, w.w_in_t, w.w_in2, 3 * d, d}, {"attn.out_proj.weight", w.w_out, w.w_out_t, w.w_out2, d, d},
+                      {"mlp.c_fc.weight", w.w_fc, w.w_fc_t, w.w_fc2, 4 * d, d}, {"mlp.c_proj.weight", w.w_proj, w.w_proj_t, w.w_proj2, d, 4 * d}};
     for (const LP& l : lps)
         if (name == l.n) {
             ARG_CHECK(numel == l.rows * l.cols, "set_weight: %s expects %zu elements, got %zu", l.n, l.rows * l.cols, numel);
+            if (t.split) { if (int rc = upload_lp_dup(m->dtype, l.p2, data, l.rows, l.cols)) return rc; }
             return upload_lp(m->dtype, l.p, l.pt, data, l.rows, l.cols);
         }
     set_error("set_weight: unknown block tensor '%s'", name.c_str());
@@ -531,15 +555,22 @@ static int block_fwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     const int i = t.layers - 1, S = nseq, d = t.d, dt = m->dtype;
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
-    TRY(launch_gather_rows(a.attn, (size_t)d * 2, t.tail_rows, t.attn_sel, (size_t)d * 2, S, d * 2, s));
+    const int sp = t.split ? 2 : 1;  // [hi | lo] operands: rows of sp * d (sp * 4 d) elements, K doubled, B = [W | W]
+    const size_t esz = 2;
+    TRY(launch_gather_rows(a.attn, (size_t)sp * d * esz, t.tail_rows, t.attn_sel, (size_t)sp * d * esz, S, sp * d * (int)esz, s));
     TRY(launch_gather_rows(a.x_in, (size_t)d * 4, t.tail_rows, t.xin_sel, (size_t)d * 4, S, d * 4, s));
-    GemmArgs o; o.A = t.attn_sel; o.lda = d; o.B = w.w_out; o.ldb = d; o.M = S; o.N = d; o.K = d; o.bias = w.b_out; o.out0 = t.xmid_sel; o.ldo0 = d; o.aux = t.xin_sel; o.ldaux = d;
+    GemmArgs o; o.A = t.attn_sel; o.lda = sp * d; o.B = t.split ? w.w_out2 : w.w_out; o.ldb = sp * d; o.M = S; o.N = d; o.K = sp * d; o.bias = w.b_out;
+    o.out0 = t.xmid_sel; o.ldo0 = d; o.aux = t.xin_sel; o.ldaux = d;
     TRY(gemm_call(m, EPI_RESIDUAL, o, s));
-    LnFwdArgs l2; l2.x = t.xmid_sel; l2.ldx = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h_sel; l2.ldo = d; l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = S; l2.d = d;
+    LnFwdArgs l2; l2.x = t.xmid_sel; l2.ldx = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h_sel; l2.ldo = sp * d; l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = S; l2.d = d;
+    if (t.split) l2.out_lo = (char*)t.h_sel + (size_t)d * esz;
     TRY(launch_ln_fwd(dt, l2, s));
-    GemmArgs f; f.A = t.h_sel; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = S; f.N = 4 * d; f.K = d; f.bias = w.b_fc; f.out0 = t.u_sel; f.ldo0 = 4 * d; f.out1 = t.g_sel; f.ldo1 = 4 * d;
+    GemmArgs f; f.A = t.h_sel; f.lda = sp * d; f.B = t.split ? w.w_fc2 : w.w_fc; f.ldb = sp * d; f.M = S; f.N = 4 * d; f.K = sp * d; f.bias = w.b_fc;
+    f.out0 = t.u_sel; f.ldo0 = 4 * d; f.out1 = t.g_sel; f.ldo1 = sp * 4 * d;
+    if (t.split) f.out1_lo = (char*)t.g_sel + (size_t)4 * d * esz;
     TRY(gemm_call(m, EPI_GELU, f, s));
-    GemmArgs p; p.A = t.g_sel; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = S; p.N = d; p.K = 4 * d; p.bias = w.b_proj; p.out0 = t.xout_sel; p.ldo0 = d; p.aux = t.xmid_sel; p.ldaux = d;
+    GemmArgs p; p.A = t.g_sel; p.lda = sp * 4 * d; p.B = t.split ? w.w_proj2 : w.w_proj; p.ldb = sp * 4 * d; p.M = S; p.N = d; p.K = sp * 4 * d; p.bias = w.b_proj;
+    p.out0 = t.xout_sel; p.ldo0 = d; p.aux = t.xmid_sel; p.ldaux = d;
     TRY(gemm_call(m, EPI_RESIDUAL, p, s));
     return MUDPT_OK;
 }
@@ -556,26 +587,33 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
     const bool lp = m->lp_grad;
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
-    LnFwdArgs l1; l1.x = a.x_in; l1.ldx = d; l1.gamma = w.ln1_g; l1.beta = w.ln1_b; l1.out = t.h; l1.ldo = d; l1.mean = a.mean1; l1.rstd = a.rstd1; l1.rows = M; l1.d = d;
+    const int sp = t.split ? 2 : 1;  // split operands (Tower::split): [hi | lo] rows, K doubled, B = [W | W]
+    const size_t esz = 2;
+    LnFwdArgs l1; l1.x = a.x_in; l1.ldx = d; l1.gamma = w.ln1_g; l1.beta = w.ln1_b; l1.out = t.h; l1.ldo = sp * d; l1.mean = a.mean1; l1.rstd = a.rstd1; l1.rows = M; l1.d = d;
+    if (t.split) l1.out_lo = (char*)t.h + (size_t)d * esz;
     if (i > 0) {
         l1.x = t.a[i - 1].x_mid; l1.ldadd = d; l1.xout = a.x_in; l1.ldxout = d;
         if (lp) l1.add_lp = t.upd; else l1.add = t.upd;
         if (splice) { l1.ov_rows = splice; l1.ov_row0 = t.prompt_row0; l1.ov_n = n; l1.ov_L = t.L; }
     }
     TRY(launch_ln_fwd(dt, l1, s));
-    GemmArgs q; q.A = t.h; q.lda = d; q.B = w.w_in; q.ldb = d; q.M = M; q.N = 3 * d; q.K = d; q.bias = w.b_in; q.out0 = a.qkv; q.ldo0 = 3 * d;
+    GemmArgs q; q.A = t.h; q.lda = sp * d; q.B = t.split ? w.w_in2 : w.w_in; q.ldb = sp * d; q.M = M; q.N = 3 * d; q.K = sp * d; q.bias = w.b_in; q.out0 = a.qkv; q.ldo0 = 3 * d;
     TRY(gemm_call(m, EPI_STORE, q, s));
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
+    if (t.split) { at.ld_out = 2 * d; at.out_lo = (char*)a.attn + (size_t)d * esz; }
     TRY(launch_attn_fwd(dt, at, s));
     if (i + 1 == t.layers) return block_fwd_tail(m, t, nseq, s);
-    GemmArgs o; o.A = a.attn; o.lda = d; o.B = w.w_out; o.ldb = d; o.M = M; o.N = d; o.K = d; o.bias = w.b_out; o.out0 = t.upd; o.ldo0 = d;
+    GemmArgs o; o.A = a.attn; o.lda = sp * d; o.B = t.split ? w.w_out2 : w.w_out; o.ldb = sp * d; o.M = M; o.N = d; o.K = sp * d; o.bias = w.b_out; o.out0 = t.upd; o.ldo0 = d;
     TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, o, s));
-    LnFwdArgs l2; l2.x = a.x_in; l2.ldx = d; if (lp) l2.add_lp = t.upd; else l2.add = t.upd; l2.ldadd = d; l2.xout = a.x_mid; l2.ldxout = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = d;
+    LnFwdArgs l2; l2.x = a.x_in; l2.ldx = d; if (lp) l2.add_lp = t.upd; else l2.add = t.upd; l2.ldadd = d; l2.xout = a.x_mid; l2.ldxout = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = sp * d;
+    if (t.split) l2.out_lo = (char*)t.h + (size_t)d * esz;
     l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = M; l2.d = d;
     TRY(launch_ln_fwd(dt, l2, s));
-    GemmArgs f; f.A = t.h; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = M; f.N = 4 * d; f.K = d; f.bias = w.b_fc; f.out0 = a.u; f.ldo0 = 4 * d; f.out1 = t.g; f.ldo1 = 4 * d;
+    GemmArgs f; f.A = t.h; f.lda = sp * d; f.B = t.split ? w.w_fc2 : w.w_fc; f.ldb = sp * d; f.M = M; f.N = 4 * d; f.K = sp * d; f.bias = w.b_fc; f.out0 = a.u; f.ldo0 = 4 * d;
+    f.out1 = t.g; f.ldo1 = sp * 4 * d;
+    if (t.split) f.out1_lo = (char*)t.g + (size_t)4 * d * esz;
     TRY(gemm_call(m, EPI_GELU, f, s));
-    GemmArgs p; p.A = t.g; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = M; p.N = d; p.K = 4 * d; p.bias = w.b_proj; p.out0 = t.upd; p.ldo0 = d;
+    GemmArgs p; p.A = t.g; p.lda = sp * 4 * d; p.B = t.split ? w.w_proj2 : w.w_proj; p.ldb = sp * 4 * d; p.M = M; p.N = d; p.K = sp * 4 * d; p.bias = w.b_proj; p.out0 = t.upd; p.ldo0 = d;
     TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, p, s));
     return MUDPT_OK;
 }
@@ -601,6 +639,7 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(t.dattn, 0, (size_t)M * d * esz, s));
     TRY(launch_scatter_rows(t.dattn_sel, (size_t)d * esz, t.tail_rows, t.dattn, (size_t)d * esz, S, d * (int)esz, s));
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.dout = t.dattn; at.dqkv = t.dqkv; at.delta = t.delta; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
+    if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
     TRY(launch_attn_bwd(dt, at, s));
     GemmArgs g4; g4.A = t.dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 3 * d; g4.out0 = t.h; g4.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g4, s));
@@ -634,6 +673,7 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
     GemmArgs g3; g3.A = t.dx_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = M; g3.N = d; g3.K = d; g3.out0 = t.dattn; g3.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g3, s));
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.dout = t.dattn; at.dqkv = t.dqkv; at.delta = t.delta; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
+    if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
     TRY(launch_attn_bwd(dt, at, s));
     if (i == 0 && t.head_rows && t.layers > 1) {
         // block 0: d(x_in) on the prompt rows only (Tower::head_rows); the other rows of t.dx / t.dx_lp are left stale and
@@ -917,7 +957,8 @@ extern "C" int mudpt_set_loss_scale(mudpt_model* m, float loss_scale) {
 extern "C" int mudpt_debug_set(const char* name, int32_t value) {
     ARG_CHECK(name, "debug_set: null name");
     if (!strcmp(name, "gemm_variant")) { g_gemm_variant = value; return MUDPT_OK; }
-    if (!strcmp(name, "lp_grad")) { g_lp_grad_default = value != 0; return MUDPT_OK; }  // applies to models created afterwards
+    if (!strcmp(name, "lp_grad")) { g_lp_grad_default = value != 0; return MUDPT_OK; }
+    if (!strcmp(name, "txt_split")) { g_txt_split_default = value != 0; return MUDPT_OK; }  // applies to models created afterwards
     set_error("debug_set: unknown knob '%s'", name);
     return MUDPT_ERR_ARG;
 }

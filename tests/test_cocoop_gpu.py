@@ -9,9 +9,11 @@ from tests.helpers import GoldenCase
 
 pytestmark = pytest.mark.gpu
 
-# Same error model as tests/test_model_gpu.py (11-bit / 8-bit operands, fp32 accumulation); logit scale 14.29.
-LOGIT_RMS = {"fp16": 1e-3, "bf16": 1.6e-2}
-LOGIT_ATOL = {"fp16": 2e-3, "bf16": 3.2e-2}
+# Same bounds as tests/test_model_gpu.py: fp16 (text tower with split operands) within north_star's 1e-3 on the maximum for
+# ViT-B/16 (measured max 3.1e-4), 1.5x that for the tiny shape (measured 9.5e-4); logit scale 14.29.
+LOGIT_RMS = {"fp16": 5e-4, "bf16": 1.6e-2}
+LOGIT_ATOL = {"fp16": 1e-3, "bf16": 3.2e-2}
+TINY_SLACK = 1.5
 # Gradients, relative to each tensor's RMS.  ctx behaves like MuDPT's prompts.  meta_net's gradients come from d bias_i = sum over the
 # C class prompts (and n_ctx rows) of the text-input gradient, and sum_c dlogits[i, c] = 0: the per-class terms nearly cancel, so
 # the T-precision rounding of each term is amplified relative to the surviving signal.  Bounds: RMS error / max error.
@@ -41,12 +43,13 @@ def test_logits_loss_grads_match_reference(case, dtype):
     logits = m(case.images).cpu()  # eval mode: logits (trainers/cocoop.py:198)
     err, rms = (logits - case.logits).abs().max().item(), (logits - case.logits).pow(2).mean().sqrt().item()
     print(f"{dtype}: |logit - reference| max {err:.3e} rms {rms:.3e}")
-    assert rms <= LOGIT_RMS[dtype] and err <= LOGIT_ATOL[dtype]
+    slack = TINY_SLACK if case.cfg.v_layers < 12 else 1.0
+    assert rms <= slack * LOGIT_RMS[dtype] and err <= slack * LOGIT_ATOL[dtype]
     m.train()
     loss, logits2 = m.forward_backward(case.images, case.labels, return_logits=True)  # training mode: CE inside forward (:196-197)
     torch.cuda.synchronize()
     assert torch.equal(logits2.cpu(), logits)  # same kernels, same order: bitwise
-    assert abs(loss.item() - case.loss) <= LOGIT_ATOL[dtype]
+    assert abs(loss.item() - case.loss) <= slack * LOGIT_ATOL[dtype]
     got = {k: v.detach().cpu() for k, v in m.grads().items()}
     bad = []
     for k in CO.TRAINABLE_ORDER:

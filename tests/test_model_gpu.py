@@ -10,14 +10,14 @@ pytestmark = pytest.mark.gpu
 
 # Logit tolerance.  north_star: "logits matching the reference PyTorch CPU path within 1e-3 fp16".
 # Measured on MI355X (tools/error_growth.py, ViT-B/16 B=4 golden case, 44 logits, logit scale 14.29):
-#   fp16 operands: rms 4.9e-4, max 1.35e-3;  bf16 operands: rms 7.3e-3, max 1.1e-2.
-# The fp16 error is the rounding of GEMM/attention operands to 11 bits (weights are exact: CLIP checkpoints are
-# fp16-stored) and is dominated by the text tower, whose residual stream starts at |x| ~ 0.02 and is therefore
-# made of rounded block outputs from block 0 on (text features 6.5e-4 relative, image features 1.8e-4).
-# So the 1e-3 bound is asserted on the RMS error, and the maximum over the logits gets 2x headroom; both are
-# stated here rather than loosened silently.  bf16 (8-bit significand) is 16x coarser and only sanity-bounded.
-LOGIT_RMS = {"fp16": 1e-3, "bf16": 1.6e-2}
-LOGIT_ATOL = {"fp16": 2e-3, "bf16": 3.2e-2}
+#   fp16 operands: max 6.1e-4, rms 2.7e-4 (text features 3.1e-4 relative, image features 1.7e-4);  bf16: max 1.4e-2, rms 1.0e-2.
+# fp16 mode runs the text tower with split [hi | lo] GEMM operands (Tower::split): with plain 11-bit operands the
+# text features carried 6.5e-4 of relative error and single logits reached 1.5e-3.  The ViT-B/16 case is held to the north_star
+# bound on the MAXIMUM over the logits; the 3-layer tiny shape (wider relative spread, 33 logits) gets 1.5x that.
+# bf16 (8-bit significand) is 16x coarser and only sanity-bounded.
+LOGIT_RMS = {"fp16": 5e-4, "bf16": 1.6e-2}
+LOGIT_ATOL = {"fp16": 1e-3, "bf16": 3.2e-2}
+TINY_SLACK = 1.5
 GRAD_RTOL = {"fp16": 2e-2, "bf16": 1.5e-1}  # relative to each gradient tensor's RMS
 
 
@@ -43,8 +43,9 @@ def test_logits_match_reference(case, dtype):
     err = (logits - case.logits).abs().max().item()
     rms = (logits - case.logits).pow(2).mean().sqrt().item()
     print(f"{dtype}: |logit - reference| max {err:.3e} rms {rms:.3e}")
-    assert rms <= LOGIT_RMS[dtype], rms
-    assert err <= LOGIT_ATOL[dtype], err
+    slack = TINY_SLACK if case.cfg.v_layers < 12 else 1.0
+    assert rms <= slack * LOGIT_RMS[dtype], rms
+    assert err <= slack * LOGIT_ATOL[dtype], err
     m.close()
 
 
@@ -89,8 +90,9 @@ def test_loss_and_grads_match_reference(case, dtype):
     m = build(case, dtype)
     loss, logits = m.forward_backward(case.images, case.labels, return_logits=True)
     torch.cuda.synchronize()
-    assert abs(loss.item() - case.loss) <= LOGIT_ATOL[dtype]
-    assert (logits.cpu() - case.logits).abs().max().item() <= LOGIT_ATOL[dtype]
+    slack = TINY_SLACK if case.cfg.v_layers < 12 else 1.0
+    assert abs(loss.item() - case.loss) <= slack * LOGIT_ATOL[dtype]
+    assert (logits.cpu() - case.logits).abs().max().item() <= slack * LOGIT_ATOL[dtype]
     _, _, ref = O.forward_backward(case.cfg, case.frozen, case.params, case.class_embedding, case.eot, case.images, case.labels)
     got = {k: v.detach().cpu() for k, v in m.grads().items()}
     for k in O.TRAINABLE_ORDER:
