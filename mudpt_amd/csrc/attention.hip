@@ -27,7 +27,7 @@
 
 namespace mudpt {
 
-constexpr int RS = 80;  // LDS row stride in elements (160 B)
+constexpr int RS = 64;  // LDS row stride in elements: dense 128-byte rows; 16-byte chunk c of row r sits in slot c ^ (r & 7)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float SC = 0.125f * LOG2E;  // 1 / sqrt(64) folded into the base-2 exponent
 
@@ -50,7 +50,7 @@ struct Attn {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (elem)0.f;
             if (row < L) v = *(const vec8*)(src + (size_t)row * ld + ch * 8);
-            *(vec8*)(img + row * RS + ch * 8) = v;
+            *(vec8*)(img + row * RS + ((ch ^ (row & 7)) << 3)) = v;
         }
     }
     // Two images at once, ALL global loads issued before the first LDS store (one HBM round trip per workgroup instead of
@@ -72,20 +72,22 @@ struct Attn {
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const int idx = tid + k * nthreads, row = idx >> 3, ch = idx & 7;
-            *(vec8*)(img0 + row * RS + ch * 8) = v0[k];
-            *(vec8*)(img1 + row * RS + ch * 8) = v1[k];
+            *(vec8*)(img0 + row * RS + ((ch ^ (row & 7)) << 3)) = v0[k];
+            *(vec8*)(img1 + row * RS + ((ch ^ (row & 7)) << 3)) = v1[k];
         }
     }
     // 16 x 32 row fragment (A or B operand whose k runs along the image's columns): rows row0 + (lane & 15)
     __device__ static inline vec8 rows(const elem* img, int row0, int ks, int lane) {
-        return *(const vec8*)(img + (row0 + (lane & 15)) * RS + ks * 32 + (lane >> 4) * 8);
+        const int r = row0 + (lane & 15);
+        return *(const vec8*)(img + r * RS + (((ks * 4 + (lane >> 4)) ^ (r & 7)) << 3));
     }
     // operand whose k runs along the image's ROWS (32 rows row0 .. row0 + 31) and whose row/col index is the image
     // column col0 + (lane & 15): two hardware-transposed 4 x 16 block reads; element j <-> image row
     // row0 + (j < 4 ? 4 g + j : 16 + 4 g + j - 4), g = lane >> 4 (the order pack2() produces).
     __device__ static inline vec8 cols(const elem* img, int row0, int col0, int lane) {
         const int g = lane >> 4, i = lane & 15;
-        const elem* p = img + (row0 + 4 * g + (i >> 2)) * RS + col0 + 4 * (i & 3);
+        const int rr = row0 + 4 * g + (i >> 2);  // row0 is a multiple of 16, so row rr + 16 of the second read has the same swizzle
+        const elem* p = img + rr * RS + (((((col0 >> 3) + ((i & 3) >> 1)) ^ (rr & 7)) << 3) + 4 * (i & 1));
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * RS));
         const vec4 a = __builtin_bit_cast(vec4, lo), b = __builtin_bit_cast(vec4, hi);
