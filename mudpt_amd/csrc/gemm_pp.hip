@@ -106,8 +106,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     // Tile order inside an XCD's contiguous chunk: groups of GN column tiles, all row panels of a group before the next
     // group, column fastest.  The ~32 tiles an XCD runs at once then cover ~32/GN row panels x GN weight tiles, so the GN
     // weight tiles (GN x 393 KB at K = 768) stay in the 4 MiB L2 for the whole sweep over M instead of all N/256 tiles
-    // thrashing it (measured: FETCH_SIZE of the N = 3072 GEMMs was 6.4x the algorithmic bytes with GN = N/256).
-    const int GN = (p.flags >> 8) > 0 ? (p.flags >> 8) : ntn;
+    // thrashing it.  Measured (A/B in one process): N = 3072 (12 column tiles) GN = 6: -4 %; N = 2304 (9) GN = 3: -5 %;
+    // N = 768 (3): one group.
+    const int gn_knob = (p.flags >> 8) & 0xff;
+    const int GN = gn_knob > 0 ? gn_knob : (ntn >= 12 ? 6 : (ntn >= 6 && ntn % 3 == 0 ? 3 : ntn));
     const int ntm = ntiles / ntn;
     auto tile_mn = [&](int tile, int& tm, int& tn) {
         const int tpg = ntm * GN, full = ntn / GN, ng = tile / tpg;
@@ -234,7 +236,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
             const int m_base = tm * 256 + (c_half ? h * 128 + wr * 64 : wr * 128) + frow;
             // byte offset of column `col` in row (m_base + 16 i) of a [rows][ld] array.  Rows >= M lie beyond the descriptor's
             // range (dropped / read as 0); a column beyond N moves the lane out of range.
-            auto row_off = [&](int i, int ld, int esz, int col) { return (col < p.N ? (m_base * ld + col) * esz : OOB) + i * (16 * ld * esz); };
+            const int wmask = (p.flags & 16) ? 0x3ffff : -1;  // flag 16: timing ablation, every tile writes the same 256 KiB (L2-resident)
+            auto row_off = [&](int i, int ld, int esz, int col) { return ((col < p.N ? (m_base * ld + col) * esz : OOB) + i * (16 * ld * esz)) & wmask; };
             // ---- pass 1: everything that needs a LOAD is folded into the accumulators, all loads before any store
             // (vmcnt retires in issue order: a load waited for behind a store also waits for that store's completion)
 #pragma unroll
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
             // 31-33 GB/s per CU whatever the lane -> address map), so a 128 KiB tile costs ~4 us that nothing overlaps.
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (i < ni) {  // uniform: a half tile (always the block's last item) stores 4 of the 8 sub-tile rows
+                if (i < ni && !(p.flags & 8)) {  // uniform: a half tile (always the block's last item) stores 4 of the 8 sub-tile rows; flag 8: timing ablation, no stores
                 if constexpr (OUT_F32) {
                     // natural layout: the 4 lanes of a row write 64 contiguous bytes per instruction (permuted: 16-byte pieces
                     // 64 bytes apart, measured 1.55x slower)
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                     const int off = row_off(i, p.ldo0, 2, n);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut0, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut0, off, 16, 0);
-                    if constexpr (EPI == EPI_GELU) {
+                    if (EPI == EPI_GELU && !(p.flags & 4)) {  // flag 4: timing ablation, no second output
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             o0[c] = (elem)quick_gelu(acc[i][0][c]); o0[4 + c] = (elem)quick_gelu(acc[i][1][c]);
