@@ -35,6 +35,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 using lds_s16x4 = __attribute__((address_space(3))) s16x4;
 
 int attn_padded_len(int L) { return (L + 31) / 32 * 32; }
+__device__ inline int attn_padded_len_dev(int L) { return (L + 31) / 32 * 32; }
 
 template <typename T>
 struct Attn {
@@ -490,11 +491,256 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Long sequences (L > 224: ViT-L/14@336 has 577 + n_ctx vision tokens, BASELINE configs[4]): the other operand no longer
+// fits in LDS as a whole, so it streams through a 64-row stage and the forward keeps a running (online) softmax.  Same
+// fragment conventions and inner products as the whole-sequence kernels above; one workgroup = 4 waves = 64 rows of the
+// "lane" operand.  Written for coverage of that configuration, not tuned.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ inline void stage64(typename T::elem* img0, const typename T::elem* src0, size_t ld0, typename T::elem* img1, const typename T::elem* src1,
+                               size_t ld1, int row0, int L, int tid) {
+    using vec8 = typename T::vec8;
+    using elem = typename T::elem;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {  // 64 rows x 8 chunks per image over 256 threads
+        const int idx = tid + k * 256, row = idx >> 3, ch = idx & 7;
+        vec8 a, b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] = (elem)0.f; b[i] = (elem)0.f; }
+        if (row0 + row < L) {
+            a = *(const vec8*)(src0 + (size_t)(row0 + row) * ld0 + ch * 8);
+            b = *(const vec8*)(src1 + (size_t)(row0 + row) * ld1 + ch * 8);
+        }
+        *(vec8*)(img0 + row * RS + ((ch ^ (row & 7)) << 3)) = a;
+        *(vec8*)(img1 + row * RS + ((ch ^ (row & 7)) << 3)) = b;
+    }
+}
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(AttnArgs p, int nsb) {
+    using A = Attn<T>;
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    __shared__ __attribute__((aligned(16))) elem Ks[64 * RS];
+    __shared__ __attribute__((aligned(16))) elem Vs[64 * RS];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = blockIdx.x / nsb, sb = blockIdx.x - pair * nsb, b = pair / p.H, hd = pair - b * p.H;
+    const int HD = p.H * 64, L = p.L, Lp = attn_padded_len_dev(L);
+    const size_t ld = (size_t)3 * HD;
+    const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
+    const int q = sb * 64 + wave * 16 + c;
+    const vec8 q0 = A::grow(base, ld, q, L, 0, lane), q1 = A::grow(base, ld, q, L, 1, lane);
+    float m = -INFINITY, l = 0.f;
+    f32x4 O[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nst = CAUSAL ? (sb + 1 < (L + 63) / 64 ? sb + 1 : (L + 63) / 64) : (L + 63) / 64;
+    for (int st = 0; st < nst; ++st) {
+        __syncthreads();  // everyone is done with the previous stage's images
+        stage64<T>(Ks, base + HD, ld, Vs, base + 2 * HD, ld, st * 64, L, tid);
+        __syncthreads();
+        f32x4 S[4];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            S[kt] = T::mfma16(A::rows(Ks, kt * 16, 0, lane), q0, S[kt]);
+            S[kt] = T::mfma16(A::rows(Ks, kt * 16, 1, lane), q1, S[kt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = st * 64 + kt * 16 + 4 * g + r;
+                if (key >= L || (CAUSAL && key > q)) S[kt][r] = -INFINITY;
+                mloc = fmaxf(mloc, S[kt][r]);
+            }
+        }
+        const float mnew = fmaxf(m, group_max(mloc));  // finite from the first stage on: key 0 is visible to every query
+        const float alpha = mnew == -INFINITY ? 1.f : __builtin_amdgcn_exp2f((m - mnew) * SC), nm = mnew == -INFINITY ? 0.f : -mnew * SC;
+        m = mnew;
+        l *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][r], SC, nm));
+                S[kt][r] = e;
+                l += e;
+            }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) O[dt] *= alpha;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const vec8 pb = A::pack2(S[2 * kc], S[2 * kc + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) O[dt] = T::mfma16(A::cols(Vs, kc * 32, dt * 16, lane), pb, O[dt]);
+        }
+    }
+    l = group_sum(l);
+    const size_t ldo = p.ld_out ? (size_t)p.ld_out : (size_t)HD;
+    if (q < L) {
+        const size_t off = ((size_t)b * L + q) * ldo + hd * 64;
+        if (p.out_lo) A::store_t_split((elem*)p.out + off, (elem*)p.out_lo + off, O, 1.f / l, lane);
+        else A::store_t((elem*)p.out + off, O, 1.f / l, lane);
+    }
+    if (g == 0 && p.lse && q < Lp) p.lse[(size_t)pair * Lp + q] = q < L ? m * 0.125f + __logf(l) : 0.f;
+}
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(AttnArgs p, const void* fwd_out, int nsb) {
+    using A = Attn<T>;
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    __shared__ __attribute__((aligned(16))) elem Ks[64 * RS];
+    __shared__ __attribute__((aligned(16))) elem Vs[64 * RS];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = blockIdx.x / nsb, sb = blockIdx.x - pair * nsb, b = pair / p.H, hd = pair - b * p.H;
+    const int HD = p.H * 64, L = p.L, Lp = attn_padded_len_dev(L);
+    const size_t ld = (size_t)3 * HD, ldof = p.ld_out ? (size_t)p.ld_out : (size_t)HD;
+    const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
+    const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
+    const elem* Of = (const elem*)fwd_out + (size_t)b * L * ldof + hd * 64;
+    const int q = sb * 64 + wave * 16 + c;
+    const vec8 q0 = A::grow(base, ld, q, L, 0, lane), q1 = A::grow(base, ld, q, L, 1, lane);
+    const vec8 g0 = A::grow(dO, HD, q, L, 0, lane), g1 = A::grow(dO, HD, q, L, 1, lane);
+    const vec8 o0 = A::grow(Of, ldof, q, L, 0, lane), o1 = A::grow(Of, ldof, q, L, 1, lane);
+    float delta = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) delta += (float)g0[i] * (float)o0[i] + (float)g1[i] * (float)o1[i];
+    delta = group_sum(delta);
+    const size_t stat = (size_t)pair * Lp + (q < Lp ? q : 0);
+    if (g == 0 && q < Lp) p.delta[stat] = delta;
+    const float nlse = q < L ? -p.lse[stat] * LOG2E : 0.f;
+    f32x4 dQ[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nst = CAUSAL ? (sb + 1 < (L + 63) / 64 ? sb + 1 : (L + 63) / 64) : (L + 63) / 64;
+    for (int st = 0; st < nst; ++st) {
+        __syncthreads();
+        stage64<T>(Ks, base + HD, ld, Vs, base + 2 * HD, ld, st * 64, L, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = 2 * kc + t;
+                f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {-delta, -delta, -delta, -delta};
+                S = T::mfma16(A::rows(Ks, kt * 16, 0, lane), q0, S);
+                S = T::mfma16(A::rows(Ks, kt * 16, 1, lane), q1, S);
+                dP = T::mfma16(A::rows(Vs, kt * 16, 0, lane), g0, dP);
+                dP = T::mfma16(A::rows(Vs, kt * 16, 1, lane), g1, dP);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = st * 64 + kt * 16 + 4 * g + r;
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nlse));
+                    if (key >= L || (CAUSAL && key > q)) pr = 0.f;
+                    ds[t][r] = pr * dP[r];
+                }
+            }
+            const vec8 db = A::pack2(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dQ[dt] = T::mfma16(A::cols(Ks, kc * 32, dt * 16, lane), db, dQ[dt]);
+        }
+    }
+    if (q < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + q) * ld + hd * 64, dQ, 0.125f, lane);
+}
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_tiled_kernel(AttnArgs p, int nsb) {
+    using A = Attn<T>;
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    __shared__ __attribute__((aligned(16))) elem Qs[64 * RS];
+    __shared__ __attribute__((aligned(16))) elem Gs[64 * RS];
+    __shared__ float lse_s[64], del_s[64];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = blockIdx.x / nsb, sb = blockIdx.x - pair * nsb, b = pair / p.H, hd = pair - b * p.H;
+    const int HD = p.H * 64, L = p.L, Lp = attn_padded_len_dev(L);
+    const size_t ld = (size_t)3 * HD;
+    const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
+    const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
+    const int key = sb * 64 + wave * 16 + c;
+    const vec8 k0 = A::grow(base + HD, ld, key, L, 0, lane), k1 = A::grow(base + HD, ld, key, L, 1, lane);
+    const vec8 v0 = A::grow(base + 2 * HD, ld, key, L, 0, lane), v1 = A::grow(base + 2 * HD, ld, key, L, 1, lane);
+    f32x4 dK[4], dV[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int nst = (L + 63) / 64;
+    for (int st = CAUSAL ? sb : 0; st < nst; ++st) {  // causal: query stages that hold a query >= this workgroup's first key
+        __syncthreads();
+        stage64<T>(Qs, base, ld, Gs, dO, (size_t)HD, st * 64, L, tid);
+        if (tid < 64) {
+            const int qi = st * 64 + tid;
+            lse_s[tid] = qi < L ? -p.lse[(size_t)pair * Lp + qi] * LOG2E : -INFINITY;  // padding queries: p = 0
+            del_s[tid] = qi < L ? p.delta[(size_t)pair * Lp + qi] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc) {
+            f32x4 P[2], dS[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qt = 2 * qc + t;
+                const f32x4 nl = *(const f32x4*)(lse_s + qt * 16 + 4 * g);
+                const f32x4 d4 = *(const f32x4*)(del_s + qt * 16 + 4 * g);
+                f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = -d4;
+                S = T::mfma16(A::rows(Qs, qt * 16, 0, lane), k0, S);
+                S = T::mfma16(A::rows(Qs, qt * 16, 1, lane), k1, S);
+                dP = T::mfma16(A::rows(Gs, qt * 16, 0, lane), v0, dP);
+                dP = T::mfma16(A::rows(Gs, qt * 16, 1, lane), v1, dP);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nl[r]));
+                    if (CAUSAL && key > st * 64 + qt * 16 + 4 * g + r) pr = 0.f;
+                    P[t][r] = pr;
+                    dS[t][r] = pr * dP[r];
+                }
+            }
+            const vec8 pb = A::pack2(P[0], P[1]), db = A::pack2(dS[0], dS[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dV[dt] = T::mfma16(A::cols(Gs, qc * 32, dt * 16, lane), pb, dV[dt]);
+                dK[dt] = T::mfma16(A::cols(Qs, qc * 32, dt * 16, lane), db, dK[dt]);
+            }
+        }
+    }
+    if (key < L) {
+        elem* ok = (elem*)p.dqkv + ((size_t)b * L + key) * ld + HD + hd * 64;
+        A::store_t(ok, dK, 0.125f, lane);
+        A::store_t(ok + HD, dV, 1.f, lane);
+    }
+}
+
+template <typename T, bool BWD>
+static int tiled_launch(const AttnArgs& a, hipStream_t s) {
+    const int nsb = (a.L + 63) / 64;
+    const size_t nwg = (size_t)a.B * a.H * nsb;
+    ARG_CHECK(nwg < 0x7fffffffull, "attention: too many workgroups (%zu)", nwg);
+    const dim3 grid((unsigned)nwg), block(256);
+    if (!BWD) {
+        if (a.causal) hipLaunchKernelGGL((attn_fwd_tiled_kernel<T, true>), grid, block, 0, s, a, nsb);
+        else hipLaunchKernelGGL((attn_fwd_tiled_kernel<T, false>), grid, block, 0, s, a, nsb);
+    } else {
+        if (a.causal) {
+            hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<T, true>), grid, block, 0, s, a, (const void*)a.out, nsb);
+            hipLaunchKernelGGL((attn_bwd_dkv_tiled_kernel<T, true>), grid, block, 0, s, a, nsb);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<T, false>), grid, block, 0, s, a, (const void*)a.out, nsb);
+            hipLaunchKernelGGL((attn_bwd_dkv_tiled_kernel<T, false>), grid, block, 0, s, a, nsb);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static int check(const AttnArgs& a, bool bwd) {
     ARG_CHECK(a.qkv && a.B > 0 && a.L > 0 && a.H > 0, "attention: bad arguments B=%d L=%d H=%d", a.B, a.L, a.H);
-    ARG_CHECK(a.L <= 224, "attention: L=%d exceeds the on-chip limit of 224 rows", a.L);
+    ARG_CHECK(a.L <= 4096, "attention: L=%d exceeds the supported 4096 rows", a.L);
     ARG_CHECK((uintptr_t)a.qkv % 16 == 0, "attention: qkv must be 16-byte aligned");
     ARG_CHECK((size_t)a.B * a.L * 3 * a.H * 64 * 2 < 0x7fffffffull, "attention: qkv larger than 2 GiB");  // 32-bit DMA offsets
     if (!bwd) ARG_CHECK(a.out && (uintptr_t)a.out % 16 == 0, "attention: null/unaligned out");
@@ -560,6 +806,7 @@ static int bwd_cfg(const AttnArgs& a, hipStream_t s) {
 
 template <typename T, bool BWD>
 static int dispatch(const AttnArgs& a, hipStream_t s) {
+    if (a.L > 224) return tiled_launch<T, BWD>(a, s);  // the other operand streams through 64-row stages
     const int nc = attn_padded_len(a.L) / 32;
 #define MUDPT_ATTN_CASE(N)                                                                     \
     case N:                                                                                    \

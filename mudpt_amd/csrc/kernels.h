@@ -96,8 +96,8 @@ int launch_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s);
 // ------------------------------------------------------------------------------------------------
 // Small / HBM-bound helpers
 // ------------------------------------------------------------------------------------------------
-// images fp32 [B,3,H,W] -> patches T [B*P, 3*p*p]  (im2col of the stride-p conv, clip/model.py:527-529)
-int launch_patchify(int dtype, const float* images, void* patches, int B, int image_size, int patch, hipStream_t s);
+// images fp32 [B,3,H,W] -> patches T [B*P, ldk], columns 3*p*p.. zero  (im2col of the stride-p conv, clip/model.py:527-529)
+int launch_patchify(int dtype, const float* images, void* patches, int B, int image_size, int patch, int ldk, hipStream_t s);
 // x[b, row0 + i, :] = rows[i, :] (+ add[i, :])  for i < n : CLS row, prompt rows, deep-prompt splice.
 int launch_set_rows(float* x, int B, int L, int d, int row0, int n, const float* rows, const float* add, hipStream_t s);
 // dst[r] = src[rows[r]] (gather) / dst[rows[r]] = src[r] (scatter): whole rows of row_bytes (multiple of 16), strides in bytes.

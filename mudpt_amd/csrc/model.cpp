@@ -278,15 +278,14 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     const bool cocoop = c->variant == MUDPT_VARIANT_COCOOP;
     ARG_CHECK(cocoop || c->depth > 0, "PROMPT_DEPTH should be > 0");  // trainers/mudpt.py:52
     ARG_CHECK(c->n_ctx > 0 && c->n_cls > 0 && c->max_batch > 0, "create: n_ctx, n_cls, max_batch must be positive");
-    ARG_CHECK(c->image_size % c->patch == 0 && c->patch % 8 == 0, "create: image_size %d / patch %d unsupported", c->image_size, c->patch);
+    ARG_CHECK(c->patch > 0 && c->image_size % c->patch == 0, "create: image_size %d / patch %d unsupported", c->image_size, c->patch);
     ARG_CHECK(c->v_width == c->v_heads * 64 && c->t_width == c->t_heads * 64, "create: head dim must be 64");
     ARG_CHECK(c->v_width % 64 == 0 && c->t_width % 64 == 0 && c->v_width <= 1024 && c->t_width <= 1024, "create: widths must be multiples of 64, <= 1024");
     ARG_CHECK(c->embed_dim == c->t_width, "create: embed_dim must equal t_width (visual_ctx_deep_projections output is added to text prompts)");
-    ARG_CHECK((3 * c->patch * c->patch) % 64 == 0, "create: 3*patch^2 must be a multiple of 64");
     ARG_CHECK(1 + c->n_ctx < c->ctx_len, "create: n_ctx too large for ctx_len");
     const int P = (c->image_size / c->patch) * (c->image_size / c->patch);
     const int Lv = 1 + P + (cocoop ? 0 : c->n_ctx);  // CoCoOp's image encoder is the vanilla ViT (trainers/cocoop.py:38, clip/model.py:443-496)
-    ARG_CHECK(Lv <= 224 && c->ctx_len <= 224, "create: sequence length %d/%d exceeds the on-chip attention limit (224)", Lv, c->ctx_len);
+    ARG_CHECK(Lv <= 4096 && c->ctx_len <= 4096, "create: sequence length %d/%d exceeds the attention limit (4096)", Lv, c->ctx_len);
 
     mudpt_model* m = new mudpt_model();
     m->cfg = *c;
@@ -300,7 +299,7 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     if (int r = alloc_tower(m, m->vis, dv, c->v_layers, c->v_heads, Lv, B, false, cocoop ? Lv : Lv - n)) return fail(r);
     if (int r = alloc_tower(m, m->txt, dt, c->t_layers, c->t_heads, c->ctx_len, TS, true, 1, c->dtype == MUDPT_F16 && g_txt_split_default)) return fail(r);
     auto body = [&]() -> int {
-        const int K0 = 3 * c->patch * c->patch;
+        const int K0 = (3 * c->patch * c->patch + 63) / 64 * 64;  // conv-as-GEMM K, zero-padded to the GEMM's granularity (ViT-L/14: 588 -> 640)
         ALLOC(m->conv_w, (size_t)dv * K0 * 2);
         ALLOC(m->cls, dv * 4); ALLOC(m->vpos, (size_t)(1 + P) * dv * 4);
         ALLOC(m->ln_pre_g, dv * 4); ALLOC(m->ln_pre_b, dv * 4); ALLOC(m->ln_post_g, dv * 4); ALLOC(m->ln_post_b, dv * 4);
@@ -453,7 +452,13 @@ extern "C" int mudpt_set_weight(mudpt_model* m, const char* key, const float* da
 #define EXPECT(n) ARG_CHECK(numel == (size_t)(n), "set_weight: %s expects %zu elements, got %zu", key, (size_t)(n), numel)
     if (k.rfind("visual.transformer.resblocks.", 0) == 0) rc = blk("visual.transformer.resblocks.", m->vis);
     else if (k.rfind("transformer.resblocks.", 0) == 0) rc = blk("transformer.resblocks.", m->txt);
-    else if (k == "visual.conv1.weight") { EXPECT(dv * 3 * c.patch * c.patch); rc = upload_lp(m->dtype, m->conv_w, nullptr, data, dv, 3 * c.patch * c.patch); }
+    else if (k == "visual.conv1.weight") {
+        EXPECT(dv * 3 * c.patch * c.patch);
+        const size_t k0 = (size_t)3 * c.patch * c.patch, k0p = (k0 + 63) / 64 * 64;
+        std::vector<float> padded(dv * k0p, 0.f);  // rows zero-padded like the im2col rows
+        for (size_t r = 0; r < dv; ++r) memcpy(&padded[r * k0p], data + r * k0, k0 * 4);
+        rc = upload_lp(m->dtype, m->conv_w, nullptr, padded.data(), dv, k0p);
+    }
     else if (k == "visual.class_embedding") { EXPECT(dv); rc = upload_f32(m->cls, data, numel); }
     else if (k == "visual.positional_embedding") { EXPECT((1 + P) * dv); rc = upload_f32(m->vpos, data, numel); }
     else if (k == "visual.ln_pre.weight") { EXPECT(dv); rc = upload_f32(m->ln_pre_g, data, numel); }
@@ -703,9 +708,9 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
 static int vision_forward(mudpt_model* m, const float* images, int B, hipStream_t s) {
     const mudpt_config& c = m->cfg;
     const int dv = c.v_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1;
-    const int P = (c.image_size / c.patch) * (c.image_size / c.patch), Lv = m->vis.L, K0 = 3 * c.patch * c.patch;
+    const int P = (c.image_size / c.patch) * (c.image_size / c.patch), Lv = m->vis.L, K0 = (3 * c.patch * c.patch + 63) / 64 * 64;
     float* Pm = m->params;
-    TRY(launch_patchify(m->dtype, images, m->patches, B, c.image_size, c.patch, s));
+    TRY(launch_patchify(m->dtype, images, m->patches, B, c.image_size, c.patch, K0, s));
     GemmArgs pe; pe.A = m->patches; pe.lda = K0; pe.B = m->conv_w; pe.ldb = K0; pe.M = B * P; pe.N = dv; pe.K = K0; pe.out0 = m->xpre; pe.ldo0 = dv;
     pe.patches = P; pe.seq_len = Lv; pe.pos = m->vpos;
     TRY(gemm_call(m, EPI_PATCH, pe, s));

@@ -78,6 +78,10 @@ class Config:
 
 
 VIT_B16 = Config()
+# CLIP ViT-L/14@336px with MuDPT depth 24 (BASELINE configs[4]): 576 patches + CLS + 4 prompt rows = 581 vision tokens; the text
+# tower has 12 layers, so deep prompts 12..22 are never consumed and get zero gradient
+VIT_L14_336 = Config(image_size=336, patch=14, v_width=1024, v_layers=24, v_heads=16, t_width=768, t_layers=12, t_heads=12,
+                     ctx_len=77, vocab=49408, embed_dim=768, n_ctx=4, depth=24)
 # Small shape used by fast tests: head_dim stays 64 (vision_heads = width // 64, clip/model.py:695),
 # embed_dim == t_width as the reference requires, depth < layers so that
 # "layers >= depth keep propagating prompt outputs" is exercised.

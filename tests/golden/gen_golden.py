@@ -254,6 +254,9 @@ if __name__ == "__main__":
     if "--tokenizer-only" in sys.argv:
         run_tokenizer()
         sys.exit(0)
+    if "--vitl-only" in sys.argv:
+        run(O.VIT_L14_336, "mudpt_vitl14_336_b1", "a photo of a", batch=1, frozen_seed=5, train_seed=6, image_seed=77, sample_big=True)
+        sys.exit(0)
     if "--cocoop-only" in sys.argv:
         run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
         run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)
@@ -261,6 +264,7 @@ if __name__ == "__main__":
     run(O.TINY, "mudpt_tiny", "a photo", batch=3, frozen_seed=11, train_seed=12, image_seed=13, sample_big=False)
     run(O.VIT_B16, "mudpt_vitb16_b4", "a photo of a", batch=4, frozen_seed=0, train_seed=1, image_seed=1234,
         sample_big=True)
+    run(O.VIT_L14_336, "mudpt_vitl14_336_b1", "a photo of a", batch=1, frozen_seed=5, train_seed=6, image_seed=77, sample_big=True)
     run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
     run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)
     run_tokenizer()

@@ -209,7 +209,9 @@ def test_layernorm_gather_scatter(lib):
     torch.testing.assert_close(dx.cpu(), full, atol=2e-5, rtol=2e-5)
 
 
-ATTN_CASES = [(3, 201, 12, False), (11, 77, 8, True), (2, 7, 3, False), (2, 33, 2, True), (1, 224, 1, False), (2, 64, 2, True)]
+ATTN_CASES = [(3, 201, 12, False), (11, 77, 8, True), (2, 7, 3, False), (2, 33, 2, True), (1, 224, 1, False), (2, 64, 2, True),
+              # L > 224: the tiled (online-softmax) kernels; 581 = ViT-L/14@336's 577 tokens + 4 prompt rows (BASELINE configs[4])
+              (2, 300, 2, False), (1, 581, 3, False), (2, 260, 2, True), (1, 225, 1, False)]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

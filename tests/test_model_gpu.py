@@ -31,7 +31,7 @@ def build(case: GoldenCase, dtype: str, max_batch=None):
     return m
 
 
-@pytest.fixture(scope="module", params=["mudpt_tiny", "mudpt_vitb16_b4"])
+@pytest.fixture(scope="module", params=["mudpt_tiny", "mudpt_vitb16_b4", "mudpt_vitl14_336_b1"])
 def case(request):
     return GoldenCase(request.param)
 
