@@ -33,7 +33,7 @@ def flops_per_step(shape, B: int, C: int) -> float:
         return L * layers * (2 * 24 * d * d + 3 * 4 * L * d)
     P = (shape.image_size // shape.patch) ** 2
     Lv = 1 + P + shape.n_ctx
-    vis = tower(shape.v_width, Lv, shape.v_layers) + 2 * P * (3 * shape.patch ** 2) * shape.v_width
+    vis = tower(shape.v_width, Lv, shape.v_layers) + 2 * P * (3 * shape.patch ** 2) * shape.v_width  # patch embed forward only
     txt = tower(shape.t_width, shape.ctx_len, shape.t_layers)
     return float(B) * vis + float(C) * txt
 
@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--classes", type=int, default=11)
+    ap.add_argument("--arch", default="vit_b16", choices=["vit_b16", "vit_l14_336"], help="vit_l14_336 = BASELINE configs[4] (not the headline line)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
@@ -101,6 +102,8 @@ def main():
     if args.fp32_streams:
         capi.check(capi.load().mudpt_debug_set(b"lp_grad", 0))
     shape = ModelShape()  # CLIP ViT-B/16, n_ctx 4, depth 12
+    if args.arch == "vit_l14_336":
+        shape = ModelShape(image_size=336, patch=14, v_width=1024, v_layers=24, v_heads=16, t_width=768, t_layers=12, t_heads=12, embed_dim=768, n_ctx=4, depth=24)
     B, C = args.batch, args.classes
     tok = synth.bench_tokenized_prompts() if C == 11 else synth.synthetic_tokenized_prompts(C)
     model = CustomCLIP(shape, synth.random_clip_state(shape, seed=0), tok, ctx_token_ids=synth.CTX_INIT_TOKENS,
@@ -161,11 +164,11 @@ def main():
         ms = elapsed / args.steps * 1e3
         step_flop = flops_per_step(shape, B, C)
         out = {
-            "metric": "images/sec fwd+bwd ViT-B/16 MuDPT", "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s",
+            "metric": "images/sec fwd+bwd ViT-B/16 MuDPT" if args.arch == "vit_b16" else "images/sec fwd+bwd ViT-L/14@336 MuDPT", "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"MuDPT ViT-B/16 fwd+bwd+SGD, batch {B}/GPU, {C} class prompts, n_ctx 4, depth 12, "
-                                   f"synthetic 224x224 N(0,1) images, random-init frozen CLIP (BASELINE configs[1])",
+            "config": {"workload": f"MuDPT {'ViT-B/16' if args.arch == 'vit_b16' else 'ViT-L/14@336'} fwd+bwd+SGD, batch {B}/GPU, {C} class prompts, n_ctx 4, depth 12, "
+                                   f"synthetic {shape.image_size}x{shape.image_size} N(0,1) images, random-init frozen CLIP (BASELINE configs[{1 if args.arch == 'vit_b16' else 4}])",
                        "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss_v, 4),
                        "step_tflop": round(step_flop / 1e12, 3)},
         }
