@@ -167,7 +167,7 @@ def main():
             "metric": "images/sec fwd+bwd ViT-B/16 MuDPT" if args.arch == "vit_b16" else "images/sec fwd+bwd ViT-L/14@336 MuDPT", "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"MuDPT {'ViT-B/16' if args.arch == 'vit_b16' else 'ViT-L/14@336'} fwd+bwd+SGD, batch {B}/GPU, {C} class prompts, n_ctx 4, depth 12, "
+            "config": {"workload": f"MuDPT {'ViT-B/16' if args.arch == 'vit_b16' else 'ViT-L/14@336'} fwd+bwd+SGD, batch {B}/GPU, {C} class prompts, n_ctx {shape.n_ctx}, depth {shape.depth}, "
                                    f"synthetic {shape.image_size}x{shape.image_size} N(0,1) images, random-init frozen CLIP (BASELINE configs[{1 if args.arch == 'vit_b16' else 4}])",
                        "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss_v, 4),
                        "step_tflop": round(step_flop / 1e12, 3)},
