@@ -236,9 +236,6 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     GemmArgs b = a;
     if (g_gemm_variant & 0x100) b.flags |= 1;
     if (g_gemm_variant & 0x200) b.flags |= 2;  // gemm_pp: no half tiles in the last wave
-    if (g_gemm_variant & 0x400) b.flags |= 4;  // gemm_pp timing ablations (wrong results): no second output / no stores at all
-    if (g_gemm_variant & 0x800) b.flags |= 8;
-    if (g_gemm_variant & 0x100000) b.flags |= 16;
     b.flags |= ((g_gemm_variant >> 12) & 0xff) << 8;  // bits 12..19 of the knob: column-tile group width GN of gemm_pp (0 = default)
     // default: the persistent ping-pong kernel for the big GEMMs whose epilogue needs no operand load besides bias / u
     if (gemm_uses_pp(epi, a)) return launch_gemm_pp(dtype, epi, b, s);

@@ -236,8 +236,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
             const int m_base = tm * 256 + (c_half ? h * 128 + wr * 64 : wr * 128) + frow;
             // byte offset of column `col` in row (m_base + 16 i) of a [rows][ld] array.  Rows >= M lie beyond the descriptor's
             // range (dropped / read as 0); a column beyond N moves the lane out of range.
-            const int wmask = (p.flags & 16) ? 0x3ffff : -1;  // flag 16: timing ablation, every tile writes the same 256 KiB (L2-resident)
-            auto row_off = [&](int i, int ld, int esz, int col) { return ((col < p.N ? (m_base * ld + col) * esz : OOB) + i * (16 * ld * esz)) & wmask; };
+            auto row_off = [&](int i, int ld, int esz, int col) { return (col < p.N ? (m_base * ld + col) * esz : OOB) + i * (16 * ld * esz); };
             // ---- pass 1: everything that needs a LOAD is folded into the accumulators, all loads before any store
             // (vmcnt retires in issue order: a load waited for behind a store also waits for that store's completion)
 #pragma unroll
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
             // 31-33 GB/s per CU whatever the lane -> address map), so a 128 KiB tile costs ~4 us that nothing overlaps.
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (i < ni && !(p.flags & 8)) {  // uniform: a half tile (always the block's last item) stores 4 of the 8 sub-tile rows; flag 8: timing ablation, no stores
+                if (i < ni) {  // uniform: a half tile (always the block's last item) stores 4 of the 8 sub-tile rows
                 if constexpr (OUT_F32) {
                     // natural layout: the 4 lanes of a row write 64 contiguous bytes per instruction (permuted: 16-byte pieces
                     // 64 bytes apart, measured 1.55x slower)
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                     const int off = row_off(i, p.ldo0, 2, n);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut0, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut0, off, 16, 0);
-                    if (EPI == EPI_GELU && !(p.flags & 4)) {  // flag 4: timing ablation, no second output
+                    if constexpr (EPI == EPI_GELU) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             o0[c] = (elem)quick_gelu(acc[i][0][c]); o0[4 + c] = (elem)quick_gelu(acc[i][1][c]);
