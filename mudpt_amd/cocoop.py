@@ -14,7 +14,7 @@ import os.path as osp
 from . import parallel, synth
 from .model import CustomCLIP, ModelShape
 from .trainer import (PREC_TO_DTYPE, TRAINER_REGISTRY, TrainerX, build_lr_scheduler, build_optimizer, load_checkpoint,
-                      load_clip_state_dict, tokenize_prompts)
+                      load_clip_state_dict, load_pretrained_weights, tokenize_prompts)
 
 
 @TRAINER_REGISTRY.register()
@@ -59,6 +59,8 @@ class CoCoOp(TrainerX):
                                 dtype=PREC_TO_DTYPE[cc.PREC], device=f"cuda:{local}", seed=cfg.SEED, variant="cocoop")
         print("Turning off gradients in both the image and the text encoder")  # structural: the module owns the 5 trainables only
         print(f"Parameters to be updated: {set(self.model.param_names)}")
+        if cfg.MODEL.INIT_WEIGHTS:  # :234-235
+            load_pretrained_weights(self.model.prompt_learner, cfg.MODEL.INIT_WEIGHTS)
         # NOTE: only give prompt_learner to the optimizer (:237)
         self.optim = build_optimizer(self.model.prompt_learner, cfg.OPTIM)
         self.sched = build_lr_scheduler(self.optim, cfg.OPTIM)

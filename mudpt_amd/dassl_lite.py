@@ -102,6 +102,27 @@ def load_checkpoint(path):
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
+def load_pretrained_weights(model, weight_path):
+    """Dassl's load_pretrained_weights: copy the checkpoint entries whose name and shape match, report the rest."""
+    ckpt = load_checkpoint(weight_path)
+    state = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+    own = model.state_dict()
+    matched, discarded = [], []
+    for k, v in state.items():
+        k = k[7:] if k.startswith("module.") else k
+        if k in own and own[k].shape == v.shape:
+            own[k].copy_(v)
+            matched.append(k)
+        else:
+            discarded.append(k)
+    if not matched:
+        print(f'Cannot load {weight_path} (check the key names manually)')
+    else:
+        print(f"Successfully loaded pretrained weights from {weight_path}")
+        if discarded:
+            print(f"Layers discarded due to unmatched keys or size: {discarded}")
+
+
 class _SyntheticDataset:
     def __init__(self, classnames):
         self.classnames = classnames

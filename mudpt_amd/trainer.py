@@ -15,10 +15,10 @@ import torch
 try:  # the real framework, when present
     from dassl.engine import TRAINER_REGISTRY, TrainerX
     from dassl.optim import build_optimizer, build_lr_scheduler
-    from dassl.utils import load_checkpoint
+    from dassl.utils import load_checkpoint, load_pretrained_weights
     HAVE_DASSL = True
 except ImportError:  # Dassl is not installed in the build image nor on the GPU box
-    from .dassl_lite import TRAINER_REGISTRY, TrainerX, build_optimizer, build_lr_scheduler, load_checkpoint
+    from .dassl_lite import TRAINER_REGISTRY, TrainerX, build_optimizer, build_lr_scheduler, load_checkpoint, load_pretrained_weights
     HAVE_DASSL = False
 
 from . import parallel, synth
@@ -108,6 +108,10 @@ class MuDPT(TrainerX):
                                 dtype=PREC_TO_DTYPE[mc.PREC], device=f"cuda:{local}", seed=cfg.SEED)
         # the freeze rule of trainers/mudpt.py:205-218 is structural here: the module only owns the 10 trainables
         print(f"Parameters to be updated: {set(self.model.param_names)}")
+        if cfg.MODEL.INIT_WEIGHTS:
+            # trainers/mudpt.py:220-221 passes self.model.prompt_learner, an attribute that does not exist; the
+            # evident intent -- initialise the trainables from a checkpoint -- is applied to the module that owns them
+            load_pretrained_weights(self.model, cfg.MODEL.INIT_WEIGHTS)
 
         self.optim = build_optimizer(self.model, cfg.OPTIM)
         self.sched = build_lr_scheduler(self.optim, cfg.OPTIM)

@@ -75,3 +75,13 @@ def test_constant_warmup_cosine_schedule():
     assert lrs[0] == pytest.approx(1e-5)  # WARMUP_CONS_LR for WARMUP_EPOCH = 1
     assert lrs[1] == pytest.approx(0.5 * 0.0025 * (1 + math.cos(math.pi * 1 / 10)))
     assert lrs[-1] < lrs[1]
+
+
+def test_load_pretrained_weights_matches_names_and_shapes(tmp_path):
+    """MODEL.INIT_WEIGHTS (trainers/mudpt.py:220-221, trainers/cocoop.py:234-235): Dassl's name + shape matching."""
+    src, dst = torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)
+    path = tmp_path / "w.pth.tar"
+    torch.save({"state_dict": {"weight": src.weight.detach(), "bias": torch.zeros(5), "extra": torch.ones(1)}, "epoch": 3}, path)
+    before_bias = dst.bias.detach().clone()
+    dassl_lite.load_pretrained_weights(dst, str(path))
+    assert torch.equal(dst.weight, src.weight) and torch.equal(dst.bias, before_bias)  # wrong-shaped bias is discarded
