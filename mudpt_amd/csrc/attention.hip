@@ -91,11 +91,9 @@ struct Attn {
         const elem* p = img + rr * RS + (((((col0 >> 3) + ((i & 3) >> 1)) ^ (rr & 7)) << 3) + 4 * (i & 1));
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * RS));
-        const vec4 a = __builtin_bit_cast(vec4, lo), b = __builtin_bit_cast(vec4, hi);
-        vec8 r;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { r[k] = a[k]; r[4 + k] = b[k]; }
-        return r;
+        // plain concatenation of the two 64-bit results into the 128-bit MFMA operand: no element moves
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        return __builtin_bit_cast(vec8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
     // accumulators of two consecutive 16-row tiles -> the 32-deep operand contracting over those rows
     __device__ static inline vec8 pack2(const f32x4& x0, const f32x4& x1) {
