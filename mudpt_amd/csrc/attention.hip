@@ -359,8 +359,15 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
     __syncthreads();
     const Frags fb = fetch(qbB);
 
+    const int qb_sel = p.sel_rows ? (p.sel_rows[b] - b * L) >> 4 : -1;
     auto block = [&](int qb, const Frags& f) {
         const int q = qb * 16 + c;
+        if (qb_sel >= 0 && qb != qb_sel) {  // dO = 0 on every row of this block: delta = 0, dQ = 0
+            if (g == 0) p.delta[((size_t)b * p.H + hd) * Lp + q] = 0.f;
+            const f32x4 z[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (q < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + q) * ld + hd * 64, z, 0.f, lane);
+            return;
+        }
         const vec8 q0 = f.q0, q1 = f.q1, g0 = f.g0, g1 = f.g1, o0 = f.o0, o1 = f.o1;
         float delta = 0.f;
 #pragma unroll
@@ -443,14 +450,17 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
     }
     __syncthreads();
 
+    const int qc_sel = p.sel_rows ? (p.sel_rows[b] - b * L) >> 5 : -1;  // dO is zero outside this 32-query chunk
     auto block = [&](int kb, const Frags& f) {
         const int key = kb * 16 + c;
         const vec8 k0 = f.k0, k1 = f.k1, v0 = f.v0, v1 = f.v1;
         f32x4 dK[4], dV[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const int qc_lo = CAUSAL ? (kb >> 1) : 0;  // query chunks that hold a query >= this block's first key
+        const int qc0 = qc_sel >= 0 ? (qc_sel > qc_lo ? qc_sel : qc_lo) : qc_lo, qc1 = qc_sel >= 0 ? qc_sel + 1 : NC;
 #pragma unroll 1
-        for (int qc = CAUSAL ? (kb >> 1) : 0; qc < NC; ++qc) {  // query chunks that hold a query >= this block's first key
+        for (int qc = qc0; qc < qc1; ++qc) {
             f32x4 P[2], dS[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -599,6 +609,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(AttnArgs p, cons
     const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
     const elem* Of = (const elem*)fwd_out + (size_t)b * L * ldof + hd * 64;
     const int q = sb * 64 + wave * 16 + c;
+    if (p.sel_rows && ((p.sel_rows[b] - b * L) >> 6) != sb) {  // dO = 0 on this workgroup's 64 queries (uniform branch)
+        if (g == 0 && q < Lp) p.delta[(size_t)pair * Lp + q] = 0.f;
+        const f32x4 z[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (q < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + q) * ld + hd * 64, z, 0.f, lane);
+        return;
+    }
     const vec8 q0 = A::grow(base, ld, q, L, 0, lane), q1 = A::grow(base, ld, q, L, 1, lane);
     const vec8 g0 = A::grow(dO, HD, q, L, 0, lane), g1 = A::grow(dO, HD, q, L, 1, lane);
     const vec8 o0 = A::grow(Of, ldof, q, L, 0, lane), o1 = A::grow(Of, ldof, q, L, 1, lane);
@@ -665,8 +681,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_tiled_kernel(AttnArgs p, int
     f32x4 dK[4], dV[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const int nst = (L + 63) / 64;
-    for (int st = CAUSAL ? sb : 0; st < nst; ++st) {  // causal: query stages that hold a query >= this workgroup's first key
+    const int st_sel = p.sel_rows ? (p.sel_rows[b] - b * L) >> 6 : -1;  // dO is zero outside this 64-query stage
+    const int st_lo = CAUSAL ? sb : 0;  // causal: query stages that hold a query >= this workgroup's first key
+    const int st0 = st_sel >= 0 ? (st_sel > st_lo ? st_sel : st_lo) : st_lo, nst = st_sel >= 0 ? st_sel + 1 : (L + 63) / 64;
+    for (int st = st0; st < nst; ++st) {
         __syncthreads();
         stage64<T>(Qs, base, ld, Gs, dO, (size_t)HD, st * 64, L, tid);
         if (tid < 64) {

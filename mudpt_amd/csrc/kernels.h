@@ -87,6 +87,9 @@ struct AttnArgs {
     const void* dout = nullptr; // bwd: T [B, L, H*64]
     void* dqkv = nullptr;       // bwd: T [B, L, 3*H*64]
     float* delta = nullptr;     // bwd scratch [B, H, Lp]
+    // bwd, optional: dout is zero except on ONE row per sequence, token row sel_rows[b] (the last block: only the CLS / EOT row of its
+    // output is used): dQ is computed for that row's 16-query block only (zero elsewhere) and dK / dV sum over that block's chunk
+    const int* sel_rows = nullptr;
     int B = 0, L = 0, H = 0; bool causal = false;
 };
 int attn_padded_len(int L);
