@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     const size_t st = (p.by_token || p.stats_by_token) ? t : (size_t)r;  // row of the statistics
     const float mean = p.mean[st], rstd = p.rstd[st];
     f32x4 xh[LN_MAXV], g[LN_MAXV];
+    typename T::vec4 rv[LN_MAXV];  // the T residual gradient, fetched with the other operands so its latency hides behind the reduction
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
         if (i < d4) {
             const f32x4 xv = x[i];
             const f32x4 gm = ((const f32x4*)p.gamma)[i];
+            if (p.dres_lp) rv[k] = ((const typename T::vec4*)((const elem*)p.dres_lp + t * p.lddres))[i];
             f32x4 dy;
             if constexpr (DY_F32) {
                 dy = ((const f32x4*)((const float*)p.dy + sr * p.lddy))[i];
@@ -126,8 +128,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
             for (int j = 0; j < 4; ++j) dx[j] = rstd * (g[k][j] - c1 - xh[k][j] * c2);
             if (p.dres) dx += ((const f32x4*)(p.dres + t * p.lddres))[i];
             if (p.dres_lp) {  // the gradient stream itself is kept in T (bf16 mode): no fp32 copy to read or write
-                const typename T::vec4 rv = ((const typename T::vec4*)((const elem*)p.dres_lp + t * p.lddres))[i];
-                dx += f32x4{(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]};
+                dx += f32x4{(float)rv[k][0], (float)rv[k][1], (float)rv[k][2], (float)rv[k][3]};
             }
             if (p.dx) ((f32x4*)(p.dx + t * p.lddx))[i] = dx;
             if (p.dx_lp) {

@@ -181,6 +181,7 @@ static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s) 
 }
 
 static bool g_lp_grad_default = true;
+static bool g_txt_trim_default = true;   // run the text tower on positions 0..max(eot) only; mudpt_debug_set("txt_trim")
 static bool g_txt_split_default = true;  // fp16 mode: split operands in the text tower (Tower::split); mudpt_debug_set("txt_split")
 
 static const char* kParamNames[10] = {
@@ -336,13 +337,9 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
         HIP_TRY(hipMemcpy(m->cls_rows, cr.data(), cr.size() * 4, hipMemcpyHostToDevice));
         m->vis.tail_rows = m->cls_rows;
         m->vis.head_rows = cocoop ? nullptr : m->vprompt_rows;
-        std::vector<int> tr((size_t)TS * n);
-        for (int cc = 0; cc < TS; ++cc)
-            for (int i = 0; i < n; ++i) tr[(size_t)cc * n + i] = cc * c->ctx_len + 1 + i;  // ctx rows 1..n (trainers/mudpt.py:97-115)
-        ALLOC(m->tprompt_rows, tr.size() * 4);
-        HIP_TRY(hipMemcpy(m->tprompt_rows, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
-        m->txt.head_rows = m->tprompt_rows;
-        m->txt.tail_rows = m->eot_rows;  // filled by mudpt_set_class_prompts
+        ALLOC(m->tprompt_rows, (size_t)TS * n * 4);
+        m->txt.head_rows = m->tprompt_rows;  // ctx rows of every prompt; this table and the next are filled by mudpt_set_class_prompts
+        m->txt.tail_rows = m->eot_rows;
         HIP_TRY(hipMemcpy(m->vprompt_rows, pr.data(), pr.size() * 4, hipMemcpyHostToDevice));
         return MUDPT_OK;
     };
@@ -486,18 +483,34 @@ extern "C" int mudpt_set_class_prompts(mudpt_model* m, const float* emb, const i
         if (k == "positional_embedding") { set_error("set_class_prompts: set 'positional_embedding' first"); return MUDPT_ERR_STATE; }
     const mudpt_config& c = m->cfg;
     const size_t C = c.n_cls, L = c.ctx_len, d = c.t_width;
-    std::vector<float> pos(L * d), ep(C * L * d);
-    HIP_TRY(hipMemcpy(pos.data(), m->tpos, pos.size() * 4, hipMemcpyDeviceToHost));
-    const size_t reps = m->cocoop ? (size_t)c.max_batch : 1;  // CoCoOp: sequence i * C + c for every image i
-    std::vector<int> rows(C * reps);
+    // The text tower is causal (clip/model.py:407-413 build_attention_mask) and only the EOT row of each prompt is used
+    // (trainers/mudpt.py:154): positions behind the last EOT of the class set influence neither a used output nor a gradient,
+    // so the tower runs on the first Le = max(eot) + 1 positions of every prompt ("a photo of a <name>." ends at position 7-9
+    // of 77).  Row-wise operators and causal attention make the kept rows bit-identical to the full-length run;
+    // mudpt_debug_set("txt_trim", 0) keeps all ctx_len positions (A/B runs, tests).
+    int max_eot = 0;
     for (size_t cc = 0; cc < C; ++cc) {
         ARG_CHECK(eot[cc] >= 0 && eot[cc] < (int)L, "set_class_prompts: eot index %d out of range", eot[cc]);
-        for (size_t i = 0; i < reps; ++i) rows[i * C + cc] = (int)((i * C + cc) * L) + eot[cc];
-        for (size_t i = 0; i < L * d; ++i) ep[cc * L * d + i] = emb[cc * L * d + i] + pos[i];  // trainers/mudpt.py:143
+        max_eot = std::max(max_eot, (int)eot[cc]);
     }
+    const size_t Le = g_txt_trim_default ? (size_t)std::max(max_eot + 1, c.n_ctx + 2) : L;
+    m->txt.L = (int)Le;
+    m->txt.Lp = attn_padded_len((int)Le);
+    std::vector<float> pos(L * d), ep(C * Le * d);
+    HIP_TRY(hipMemcpy(pos.data(), m->tpos, pos.size() * 4, hipMemcpyDeviceToHost));
+    const size_t reps = m->cocoop ? (size_t)c.max_batch : 1;  // CoCoOp: sequence i * C + c for every image i
+    std::vector<int> rows(C * reps), tr(C * reps * c.n_ctx);
+    for (size_t cc = 0; cc < C; ++cc) {
+        for (size_t i = 0; i < reps; ++i) rows[i * C + cc] = (int)((i * C + cc) * Le) + eot[cc];
+        for (size_t i = 0; i < Le * d; ++i) ep[cc * Le * d + i] = emb[cc * L * d + i] + pos[i];  // trainers/mudpt.py:143
+    }
+    for (size_t sq = 0; sq < C * reps; ++sq)
+        for (int i = 0; i < c.n_ctx; ++i) tr[sq * c.n_ctx + i] = (int)(sq * Le) + 1 + i;  // ctx rows 1..n (trainers/mudpt.py:97-115)
     HIP_TRY(hipMemcpy(m->emb_pos, ep.data(), ep.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->eot_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->tprompt_rows, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
     m->prompts_set = true;
+    m->text_valid = false;
     return MUDPT_OK;
 }
 
@@ -964,6 +977,7 @@ extern "C" int mudpt_debug_set(const char* name, int32_t value) {
     ARG_CHECK(name, "debug_set: null name");
     if (!strcmp(name, "gemm_variant")) { g_gemm_variant = value; return MUDPT_OK; }
     if (!strcmp(name, "lp_grad")) { g_lp_grad_default = value != 0; return MUDPT_OK; }
+    if (!strcmp(name, "txt_trim")) { g_txt_trim_default = value != 0; return MUDPT_OK; }  // applies to the next mudpt_set_class_prompts
     if (!strcmp(name, "txt_split")) { g_txt_split_default = value != 0; return MUDPT_OK; }  // applies to models created afterwards
     set_error("debug_set: unknown knob '%s'", name);
     return MUDPT_ERR_ARG;

@@ -30,11 +30,15 @@ def bench_tokenized_prompts(ctx_len: int = 77) -> torch.Tensor:
 
 
 def synthetic_tokenized_prompts(n_cls: int, n_ctx: int = 4, ctx_len: int = 77, seed: int = 7) -> torch.Tensor:
-    """Prompts shaped like "<ctx words> <1-3 name tokens> ." for synthetic class lists (e.g. 1000 ImageNet-sized)."""
+    """Prompts shaped like "<ctx words> <name tokens> ." for synthetic class lists (e.g. 1000 ImageNet-sized).  Name lengths
+    follow a long-tailed mix like BPE-tokenised ImageNet names: 70 % 1-3 tokens, 25 % 4-6, 5 % 7-12 (the longest name sets
+    the number of positions the causal text tower has to run, see mudpt_set_class_prompts)."""
     g = torch.Generator().manual_seed(seed)
     tok = torch.zeros(n_cls, ctx_len, dtype=torch.int32)
     for c in range(n_cls):
-        k = 1 + int(torch.randint(0, 3, (1,), generator=g))
+        u = float(torch.rand((), generator=g))
+        lo, hi = (1, 3) if u < 0.70 else ((4, 6) if u < 0.95 else (7, 12))
+        k = lo + int(torch.randint(0, hi - lo + 1, (1,), generator=g))
         ids = [49406] + (CTX_INIT_TOKENS * n_ctx)[:n_ctx] + [int(v) for v in torch.randint(1000, 48000, (k,), generator=g)] + [269, 49407]
         tok[c, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
     return tok

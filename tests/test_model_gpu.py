@@ -77,6 +77,7 @@ def test_block_outputs_match_reference_fp16():
             L = got.shape[1]
             rows = torch.arange(0, L, 8)
             got = got[:, ::8, ::16]
+            ref = ref[:, :len(rows)]  # the text tower runs on positions 0..max(eot) only (causal: later rows are never used)
             # x_in.{i+1} already carries block i+1's spliced prompt rows: compare the other rows only
             keep = (rows < L - n) if tower == "vis" else ((rows == 0) | (rows > n))
             rel = (got[:, keep] - ref[:, keep]).pow(2).mean().sqrt() / ref[:, keep].pow(2).mean().sqrt()
@@ -187,3 +188,28 @@ def test_eval_reuses_text_features_until_parameters_change():
     d = m(case.images)                      # training mode never reuses
     assert torch.equal(c, d)
     m.close()
+
+
+def test_text_tower_trim_changes_nothing():
+    """The text tower runs on positions 0..max(eot) of the 77 (causal mask + EOT readout: later positions are never used).
+    Logits, loss and all ten gradients must equal the full-length run up to the summation order inside attention."""
+    from mudpt_amd import capi
+    case = GoldenCase("mudpt_vitb16_b4")
+    lib = capi.load()
+    out = {}
+    for trim in (1, 0):
+        capi.check(lib.mudpt_debug_set(b"txt_trim", trim))
+        try:
+            m = build(case, "fp16")
+        finally:
+            capi.check(lib.mudpt_debug_set(b"txt_trim", 1))
+        L = m.debug_read("txt.x_in.1", len(case.labels)).numel() // (11 * case.cfg.t_width)
+        assert L == (int(case.eot.max()) + 1 if trim else case.cfg.ctx_len)
+        loss = m.forward_backward(case.images, case.labels)
+        out[trim] = (m(case.images).cpu(), loss.item(), {k: g.detach().cpu().clone() for k, g in m.grads().items()})
+        m.close()
+    torch.testing.assert_close(out[1][0], out[0][0], atol=2e-5, rtol=0)
+    assert abs(out[1][1] - out[0][1]) < 1e-6
+    for k, g in out[0][2].items():
+        scale = g.pow(2).mean().sqrt().item()
+        torch.testing.assert_close(out[1][2][k], g, atol=1e-4 * scale + 1e-12, rtol=0, msg=k)
