@@ -18,7 +18,7 @@ namespace mudpt {
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int NS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
@@ -90,14 +90,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     for (int j = 0; j < TN; ++j) boff[j] = BM * 128 + (wn * (BN / WN) + j * 16 + frow) * 128;
     const int sw = frow & 7;  // (row & 7): sub-tile bases are multiples of 16
 
+    // NS-deep ring of stages: the loads of k-tiles kt + 1 .. kt + NS - 1 are in flight while tile kt is multiplied.  NS = 2 is the
+    // plain double buffer (2 workgroups per CU hide each other's waits); NS = 4 is for grids smaller than the chip (the text
+    // tower's 99-row GEMMs: a handful of workgroups, each a pure latency chain over K).
+    static_assert(NS >= 2 && (NS & (NS - 1)) == 0, "ring depth must be a power of two");
     const int nt = p.K / BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nt) stage(st, st);
 
     for (int kt = 0; kt < nt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+        const int cur = kt & (NS - 1);
+        // tile kt has landed once at most the NS - 2 younger stages are outstanding (loads retire in issue order)
+        if (kt + NS - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (IA + IB)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // ... for every wave; and every wave is done reading the stage refilled next (read in step kt - 1)
+        if (kt + NS - 1 < nt) stage((kt + NS - 1) & (NS - 1), kt + NS - 1);
         const char* base = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -112,8 +120,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma16(bf[j], af[i], acc[i][j]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
 
     // ---- epilogue: lane holds out[m][n .. n+3], m = sub-tile row (lane & 15), n = 4 * (lane >> 4) ----
@@ -169,10 +175,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int NS = 2>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
-    constexpr int lds = 2 * (BM + BN) * 64 * 2;
-    auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI>;
+    constexpr int lds = NS * (BM + BN) * 64 * 2;
+    auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, NS>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -197,6 +203,11 @@ static int launch_epi(const GemmArgs& a, hipStream_t s) {
             default: return launch_cfg<T, 256, 256, 2, 4, EPI>(a, s);
         }
     }
+    // fewer 128 x 128 tiles than half the CUs: every workgroup is a latency chain over K -- narrower tiles (twice the
+    // workgroups) and a 4-deep ring.  gemm_variant 5 / 6 force the shallow / deep form (A/B runs).
+    const size_t t128 = (size_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const int v = g_gemm_variant & 0xff;
+    if ((t128 <= 128 && v != 5) || v == 6) return launch_cfg<T, 128, 64, 2, 2, EPI, 4>(a, s);
     return launch_cfg<T, 128, 128, 2, 2, EPI>(a, s);
 }
 
@@ -218,7 +229,7 @@ static int launch_t(int epi, const GemmArgs& a, hipStream_t s) {
 bool gemm_uses_pp(int epi, const GemmArgs& a) {
     const bool pp_epi = epi == EPI_STORE || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32;
     const int v = g_gemm_variant & 0xff;
-    return (v == 0 || v == 3) && pp_epi && !a.out1_lo && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
+    return (v == 0 || v == 3 || v == 5 || v == 6) && pp_epi && !a.out1_lo && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
            (epi != EPI_GELU_BWD || a.ldaux % 8 == 0);
 }
 

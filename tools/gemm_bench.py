@@ -22,6 +22,10 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("dqkv   bwd", 51456, 768, 2304, 0),
 ]
 
+# the text tower after the trim to max(EOT) + 1 positions: 11 prompts x 9 rows (headline), 1000 x 19 (configs[2]), CoCoOp 64 x 11 x 9
+TEXT_SHAPES = [(f"{nm} M={M}", M, N, K, e) for M in (99, 6336, 19000)
+               for nm, N, K, e in (("qkv", 1536, 512, 0), ("out", 512, 512, 5), ("fc", 2048, 512, 1), ("proj", 512, 2048, 5))]
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -31,13 +35,15 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--epi", type=int, default=-1, help="only the shapes with this epilogue")
+    ap.add_argument("--set", default="vision", choices=["vision", "text"])
     a = ap.parse_args()
+    shapes = SHAPES if a.set == "vision" else TEXT_SHAPES
     lib = capi.load()
     dt, tt = (0, torch.bfloat16) if a.dtype == "bf16" else (1, torch.float16)
     variants = [int(v) for v in a.variants.split(",")]
     P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     total = {v: 0.0 for v in variants}
-    for name, M, N, K, epi in SHAPES:
+    for name, M, N, K, epi in shapes:
         if (a.only and a.only not in name) or (a.epi >= 0 and epi != a.epi):
             continue
         A = torch.randn(M, K, device="cuda").to(tt)
@@ -69,7 +75,7 @@ def main():
         print(f"{name} M={M} N={N} K={K} epi={epi}: " + "  ".join(f"v{v}: {best[v] * 1e3:7.1f} us {fl / best[v] / 1e9:7.1f} TF/s" for v in variants), flush=True)
         for v in variants:
             total[v] += best[v]
-    layer_fl = sum(2.0 * M * N * K for _, M, N, K, _ in SHAPES)
+    layer_fl = sum(2.0 * M * N * K for _, M, N, K, _ in shapes)
     print("sum over the 8 GEMMs of one block: " + "  ".join(f"v{v}: {total[v] * 1e3:.0f} us ({layer_fl / total[v] / 1e9:.0f} TF/s)" for v in variants))
 
 
