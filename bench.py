@@ -177,11 +177,11 @@ def main():
             # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this same command
             # (PMC counters cannot be read from inside the process); the summary is committed under profiles/.
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_v3.json")
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_v5.json")
             if os.path.exists(pmc) and B == 256 and C == 11 and args.dtype == "bf16":
                 traffic = round(json.load(open(pmc))["traffic_bytes_per_launch"])
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic_v3.md)",
+                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic_v5.md)",
                                "flop_per_launch": round(gemm_flop / gemm_n),
                                "kernel": f"gemm_pp_kernel (persistent MFMA GEMM: the {gemm_n // args.steps} big vision-tower GEMM launches per step; "
                                          "achieved = executed 2MNK / event time of those launches)",
