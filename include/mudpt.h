@@ -73,7 +73,9 @@ int mudpt_destroy(mudpt_model* m);
 int mudpt_set_weight(mudpt_model* m, const char* key, const float* host_data, size_t numel);
 
 /* token_embedding(tokenized "<ctx words> <classname>.") [n_cls, ctx_len, t_width] fp32 HOST and the EOT
- * position of every class prompt; rows 1..n_ctx are replaced by the trainable ctx at run time. */
+ * position of every class prompt; rows 1..n_ctx are replaced by the trainable ctx at run time.  The text tower then runs on
+ * positions 0..max(eot_index) only: under the causal mask (clip/model.py:407-413) later positions reach neither the EOT
+ * feature (trainers/mudpt.py:154) nor any gradient. */
 int mudpt_set_class_prompts(mudpt_model* m, const float* embedding, const int32_t* eot_index);
 
 /* The 10 trainable tensors live in ONE flat fp32 bucket (= the data-parallel all-reduce payload). */
@@ -110,12 +112,13 @@ int mudpt_sgd_step(mudpt_model* m, float lr, float momentum, float weight_decay,
 int mudpt_sgd_reset(mudpt_model* m);
 
 /* Test hook: copy an internal fp32 activation of the last call to HOST memory (synchronises the device).
- * name: "vis.x_in.<i>" / "txt.x_in.<i>" (input of block i, after the prompt splice; [seq, L, d]), "vis.x_out" / "txt.x_out"
+ * name: "vis.x_in.<i>" / "txt.x_in.<i>" (input of block i, after the prompt splice; [seq, L, d], text L = max(eot) + 1), "vis.x_out" / "txt.x_out"
  * (output of the last block on the ONE row per sequence the model uses -- CLS / EOT token -- [seq, d]: the tail of the last
  * block runs on those rows only), "image_features", "text_features".  host_out may be NULL to query *numel. */
 int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* host_out, size_t capacity, size_t* numel);
 
-/* Tuning knob for A/B measurements in one process (tools/gemm_bench.py): "gemm_variant". */
+/* Tuning knobs for A/B measurements in one process (tools/gemm_bench.py, tests): "gemm_variant", "lp_grad", "txt_split",
+ * "txt_trim" (0 = run the text tower on all ctx_len positions; read by the next mudpt_set_class_prompts). */
 int mudpt_debug_set(const char* name, int32_t value);
 
 /* Measurement hook (bench.py): bracket every MFMA GEMM launch of the path with HIP events on its launch stream.
