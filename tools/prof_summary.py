@@ -13,4 +13,8 @@ with open(dst, "w") as f:
     if g:
         tot, n = sum(float(r["TotalDurationNs"]) for r in g), sum(int(r["Calls"]) for r in g)
         f.write(f"\nAll MFMA GEMM kernel instantiations: {n} launches, {tot / 1e6:.2f} ms, average {tot / n / 1e3:.1f} us per launch.\n")
+    pp = [r for r in rows if "gemm_pp_kernel" in r["Name"]]
+    if pp:
+        tot, n = sum(float(r["TotalDurationNs"]) for r in pp), sum(int(r["Calls"]) for r in pp)
+        f.write(f"\ngemm_pp_kernel (the kernel of bench.py's roofline object), all epilogues: {n} launches, {tot / 1e6:.2f} ms, average {tot / n / 1e3:.1f} us per launch.\n")
     f.write(f"\nAll kernels: {sum(float(r['TotalDurationNs']) for r in rows) / 1e6:.2f} ms.\n")
