@@ -126,15 +126,27 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(float* __restrict__ sr
     const int i = live ? idx / d : 0, c = live ? idx % d : 0;
     const int per = (B + 7) / 8, b0 = seg * per, b1 = b0 + per < B ? b0 + per : B;
     float acc = 0.f;
-    if (live)
-        for (int b = b0; b < b1; ++b) {
-            const size_t o = ((size_t)b * L + row0 + i) * d + c;
-            acc += src ? src[o] : (float)src_lp[o];  // src == null: the gradient stream lives in T only
-            if (zero_src) {
-                if (src) src[o] = 0.f;
-                if (src_lp) src_lp[o] = (typename T::elem)0.f;
+    if (live) {
+        // 16 loads in flight per thread (the loop is a pure latency chain otherwise), added in ascending b
+        const size_t step = (size_t)L * d, o0 = ((size_t)row0 + i) * d + c;
+        for (int bb = b0; bb < b1; bb += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const size_t o = (size_t)(bb + k) * step + o0;
+                v[k] = bb + k < b1 ? (src ? src[o] : (float)src_lp[o]) : 0.f;  // src == null: the gradient stream lives in T only
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                acc += v[k];
+                if (zero_src && bb + k < b1) {
+                    const size_t o = (size_t)(bb + k) * step + o0;
+                    if (src) src[o] = 0.f;
+                    if (src_lp) src_lp[o] = (typename T::elem)0.f;
+                }
             }
         }
+    }
     part[seg][cx] = acc;
     __syncthreads();
     if (seg == 0 && live) {
