@@ -354,13 +354,16 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
     // the first block's Q / dO / O fragments travel during the K / V staging, the second block's during the first block's compute
     const int nqb = (L + 15) >> 4, qbA = wave, qbB = wave + NC;
     const Frags fa = fetch(qbA);
+    // both blocks' log-sum-exp values travel with the first fragments (otherwise a dependent load at the head of each block)
+    const size_t stat0 = ((size_t)b * p.H + hd) * Lp;
+    const float lseA = p.lse[stat0 + qbA * 16 + c], lseB = qbB * 16 + c < Lp ? p.lse[stat0 + qbB * 16 + c] : 0.f;
     A::template stage2<4>(Ks, base + HD, ld, Vs, base + 2 * HD, ld, L, tid, NT);
     for (int i = tid; i < Lp; i += NT) kmask[i] = i < L ? 0.f : -INFINITY;
     __syncthreads();
     const Frags fb = fetch(qbB);
 
     const int qb_sel = p.sel_rows ? (p.sel_rows[b] - b * L) >> 4 : -1;
-    auto block = [&](int qb, const Frags& f) {
+    auto block = [&](int qb, const Frags& f, float lse_q) {
         const int q = qb * 16 + c;
         if (qb_sel >= 0 && qb != qb_sel) {  // dO = 0 on every row of this block: delta = 0, dQ = 0
             if (g == 0) p.delta[((size_t)b * p.H + hd) * Lp + q] = 0.f;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
         delta = group_sum(delta);
         const size_t stat = ((size_t)b * p.H + hd) * Lp + q;
         if (g == 0) p.delta[stat] = delta;
-        const float nlse = -p.lse[stat] * LOG2E;
+        const float nlse = -lse_q * LOG2E;
         const int nkc = CAUSAL ? (qb >> 1) + 1 : NC;
 
         f32x4 dQ[4];
@@ -406,8 +409,8 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
         }
         if (q < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + q) * ld + hd * 64, dQ, 0.125f, lane);
     };
-    if (qbA < nqb) block(qbA, fa);
-    if (qbB < nqb) block(qbB, fb);
+    if (qbA < nqb) block(qbA, fa, lseA);
+    if (qbB < nqb) block(qbB, fb, lseB);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -442,12 +445,16 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
                      A::grow(base + 2 * HD, ld, key, L, 0, lane), A::grow(base + 2 * HD, ld, key, L, 1, lane)};
     };
     const Frags fa = fetch(kbA), fb = fetch(kbB);
-    A::template stage2<4>(Qs, base, ld, Gs, dO, (size_t)HD, L, tid, NT);
-    for (int i = tid; i < Lp; i += NT) {
-        const size_t stat = ((size_t)b * p.H + hd) * Lp + i;
-        lse_s[i] = i < L ? -p.lse[stat] * LOG2E : -INFINITY;  // padding queries: p = exp2(. - inf) = 0, no per-element mask
-        del_s[i] = i < L ? p.delta[stat] : 0.f;
+    // the row statistics (Lp = NT / 2 values: one per thread) are requested with the fragments, BEFORE the staging waits for
+    // its loads: one HBM round trip per workgroup instead of two (a workgroup is a latency chain: 2 per CU)
+    float lse_v = -INFINITY, del_v = 0.f;  // padding queries: p = exp2(. - inf) = 0, no per-element mask
+    if (tid < L) {
+        const size_t stat = ((size_t)b * p.H + hd) * Lp + tid;
+        lse_v = -p.lse[stat] * LOG2E;
+        del_v = p.delta[stat];
     }
+    A::template stage2<4>(Qs, base, ld, Gs, dO, (size_t)HD, L, tid, NT);
+    if (tid < Lp) { lse_s[tid] = lse_v; del_s[tid] = del_v; }
     __syncthreads();
 
     const int qc_sel = p.sel_rows ? (p.sel_rows[b] - b * L) >> 5 : -1;  // dO is zero outside this 32-query chunk
