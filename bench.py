@@ -38,7 +38,7 @@ def flops_per_step(shape, B: int, C: int) -> float:
     return float(B) * vis + float(C) * txt
 
 
-def cpu_baseline(iters: int = 8):
+def cpu_baseline(iters: int = 24):
     """The CPU oracle (oracle/, a restatement of the reference's arithmetic pinned by tests/golden) timed on the host
     cores at BASELINE config 1's shape: ViT-B/16, n_ctx 4, depth 12, batch 4, 11 classes, fp32."""
     from oracle import mudpt_oracle as O
