@@ -171,25 +171,37 @@ int launch_reduce_rows(int dtype, float* src, void* src_lp, int B, int L, int d,
     return MUDPT_OK;
 }
 
-// ---- small fp32 GEMM: C = alpha * op(A) op(B) + bias + beta * C, 16x16 tiles through LDS
+// ---- small fp32 GEMM: C = alpha * op(A) op(B) + bias + beta * C, 16x16 output tiles, 64-deep K chunks through LDS
+// (the prompt projections: M = 4..44 rows; each workgroup is a latency chain over K, so the chunk is deep: 4 loads per operand
+// per thread in flight and one barrier pair per 64 k instead of per 16)
 __global__ __launch_bounds__(256) void sgemm_kernel(bool tA, bool tB, int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
                                                     const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
                                                     const float* __restrict__ bias) {
-    __shared__ float As[16][17], Bs[16][17];
+    constexpr int KC = 64;
+    __shared__ float As[16][KC + 1], Bs[KC][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int m = m0 + ty, n = n0 + tx;
     float acc = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        {   // As[ty][tx] = op(A)[m0 + ty][k0 + tx]
-            const int am = blockIdx.y * 16 + ty, ak = k0 + tx;
-            As[ty][tx] = (am < M && ak < K) ? (tA ? A[(size_t)ak * lda + am] : A[(size_t)am * lda + ak]) : 0.f;
-            // Bs[ty][tx] = op(B)[k0 + ty][n0 + tx]
-            const int bk = k0 + ty, bn = blockIdx.x * 16 + tx;
-            Bs[ty][tx] = (bk < K && bn < N) ? (tB ? B[(size_t)bn * ldb + bk] : B[(size_t)bk * ldb + bn]) : 0.f;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // A chunk [16][64]: thread (ty, tx) takes k = tx + 16 q of row ty when A is row-major (k contiguous), or rows tx of
+            // k = ty + 16 q when it is stored transposed (m contiguous); B likewise -- the contiguous index goes to tx
+            const int ar = tA ? tx : ty, ak = k0 + (tA ? ty : tx) + 16 * q;
+            av[q] = (m0 + ar < M && ak < K) ? (tA ? A[(size_t)ak * lda + m0 + ar] : A[(size_t)(m0 + ar) * lda + ak]) : 0.f;
+            const int bc = tB ? ty : tx, bk = k0 + (tB ? tx : ty) + 16 * q;
+            bv[q] = (n0 + bc < N && bk < K) ? (tB ? B[(size_t)(n0 + bc) * ldb + bk] : B[(size_t)bk * ldb + n0 + bc]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            As[tA ? tx : ty][(tA ? ty : tx) + 16 * q] = av[q];
+            Bs[(tB ? tx : ty) + 16 * q][tB ? ty : tx] = bv[q];
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc += As[ty][k] * Bs[k][tx];
+        for (int k = 0; k < KC; ++k) acc += As[ty][k] * Bs[k][tx];
         __syncthreads();
     }
     if (m < M && n < N) {
