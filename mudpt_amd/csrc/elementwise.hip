@@ -127,17 +127,17 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(float* __restrict__ sr
     const int per = (B + 7) / 8, b0 = seg * per, b1 = b0 + per < B ? b0 + per : B;
     float acc = 0.f;
     if (live) {
-        // 16 loads in flight per thread (the loop is a pure latency chain otherwise), added in ascending b
+        // 32 loads in flight per thread (B = 256: the whole segment in one round trip; the loop is a pure latency chain), added in ascending b
         const size_t step = (size_t)L * d, o0 = ((size_t)row0 + i) * d + c;
-        for (int bb = b0; bb < b1; bb += 16) {
-            float v[16];
+        for (int bb = b0; bb < b1; bb += 32) {
+            float v[32];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < 32; ++k) {
                 const size_t o = (size_t)(bb + k) * step + o0;
                 v[k] = bb + k < b1 ? (src ? src[o] : (float)src_lp[o]) : 0.f;  // src == null: the gradient stream lives in T only
             }
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < 32; ++k) {
                 acc += v[k];
                 if (zero_src && bb + k < b1) {
                     const size_t o = (size_t)(bb + k) * step + o0;
