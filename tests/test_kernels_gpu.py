@@ -71,11 +71,12 @@ def test_gemm_exact_integers_full_size(lib, dtype):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(804, 2304, 768), (847, 512, 2048), (77, 128, 64), (4096, 768, 3072), (33000, 768, 768),
-                                   (22100, 768, 768), (51400, 768, 192)])
+                                   (22100, 768, 768), (51400, 768, 192), (99, 512, 192), (99, 2048, 512)])
 def test_gemm_epilogues(lib, dtype, shape):
     """All fused epilogues against a float64 product.  The last two shapes leave a partial last wave of 256 x 256 tiles on 256
     CUs (261 = 256 + 5 and 603 = 2 * 256 + 91 tiles), which the persistent kernel runs as half tiles; both have a ragged
-    last row panel (22100: the lower half tile is entirely out of range)."""
+    last row panel (22100: the lower half tile is entirely out of range).  The 99-row shapes are the trimmed text tower's: the
+    small-grid kernel with its 4-deep operand ring (K = 192: exactly the ring's prologue depth)."""
     dt, tt = DT[dtype]
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N + K)
