@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MUDPT_ABI_VERSION 2
+#define MUDPT_ABI_VERSION 3
 
 #define MUDPT_OK 0
 #define MUDPT_ERR_ARG 1   /* bad argument / shape (the reference raises AssertionError, mudpt.py:52,55,190) */
@@ -145,6 +145,25 @@ int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, i
                         int32_t causal, void* stream);
 int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                         float* delta, void* dqkv, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream);
+/* LayerNorm forward with everything the transformer block fuses into it (clip/model.py:281-301): v = x[r] + add[r] (fp32 add or T
+ * add_lp, either may be NULL; row stride ldadd); rows whose position (r % ov_L) lies in [ov_row0, ov_row0 + ov_n) are REPLACED by
+ * ov_rows[(r % ov_L) - ov_row0] (the deep-prompt splice); v is written to xout (fp32, may be NULL) and normalised into out (T or fp32). */
+int mudpt_layernorm_fwd_fused(int32_t dtype, const float* x, int32_t ldx, const float* add, const void* add_lp, int32_t ldadd,
+                              const float* ov_rows, int32_t ov_row0, int32_t ov_n, int32_t ov_L, float* xout, int32_t ldxout,
+                              const float* gamma, const float* beta, void* out, int32_t ldo, int32_t out_f32, float* mean,
+                              float* rstd, int32_t rows, int32_t d, void* stream);
+/* Cosine-logit head + mean cross-entropy, forward and backward (trainers/mudpt.py:178-182,250): logits[B, C] = scale *
+ * normalise(img) . normalise(txt)^T, loss[0] = mean CE, dimg / dtxt = gradients of (grad_scale * loss) w.r.t. the RAW features.
+ * labels / loss / dimg / dtxt may be NULL (forward only).  Scratch is allocated and freed inside (synchronises: a test hook). */
+int mudpt_head(const float* img, const float* txt, const int64_t* labels, float scale, float grad_scale, int32_t B, int32_t C,
+               int32_t e, float* logits, float* loss, float* dimg, float* dtxt, void* stream);
+/* out[i, :] (+)= scale * sum_b src[b, row0 + i, :], b ascending in a fixed tree (bitwise reproducible): the backward of the prompt
+ * splice.  src_f32 [B, L, d] or its T copy src_lp (at least one non-NULL); zero_src clears the summed rows afterwards. */
+int mudpt_reduce_rows(int32_t dtype, float* src_f32, void* src_lp, int32_t B, int32_t L, int32_t d, int32_t row0, int32_t n,
+                      float* out, int32_t zero_src, int32_t accumulate, float scale, void* stream);
+/* fp32 C[M,N] = alpha * op(A) . op(B) (+ bias[N]) (+ beta * C): the prompt projections (trainers/mudpt.py:127-128, clip/model.py:539). */
+int mudpt_sgemm(int32_t transA, int32_t transB, int32_t M, int32_t N, int32_t K, float alpha, const float* A, int32_t lda,
+                const float* B, int32_t ldb, float beta, float* C, int32_t ldc, const float* bias, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "mudpt.h")
 
 BF16, F16 = 0, 1
 VARIANT_MUDPT, VARIANT_COCOOP = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD, EPI_PATCH, EPI_STORE_F32 = range(6)
 
 
@@ -58,6 +58,11 @@ SIGNATURES = {
     "mudpt_attention_padded_len": (_i32, [_i32]),
     "mudpt_attention_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mudpt_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mudpt_layernorm_fwd_fused": (_i32, [_i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
+                                         _vp, _vp, _i32, _i32, _vp]),
+    "mudpt_head": (_i32, [_vp, _vp, _vp, _f32, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mudpt_reduce_rows": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _vp]),
+    "mudpt_sgemm": (_i32, [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _i32, _vp, _i32, _f32, _vp, _i32, _vp, _vp]),
 }
 
 _lib = None

@@ -13,8 +13,8 @@ import os.path as osp
 
 from . import parallel, synth
 from .model import CustomCLIP, ModelShape
-from .trainer import (PREC_TO_DTYPE, TRAINER_REGISTRY, TrainerX, build_lr_scheduler, build_optimizer, load_checkpoint,
-                      load_clip_state_dict, load_pretrained_weights, tokenize_prompts)
+from .trainer import (TRAINER_REGISTRY, TrainerX, build_lr_scheduler, build_optimizer, data_parallel_step, load_checkpoint,
+                      load_clip_state_dict, load_pretrained_weights, precision_to_dtype, tokenize_prompts)
 
 
 @TRAINER_REGISTRY.register()
@@ -53,10 +53,12 @@ class CoCoOp(TrainerX):
         tokenized = tokenize_prompts(prompts, shape.ctx_len, near=near)
 
         print("Building custom CLIP")
-        rank, world, local = parallel.env_rank()
-        max_batch = max(cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.DATALOADER.TEST.BATCH_SIZE)
+        # one process per GPU (the reference: nn.DataParallel in one process): join the process group torch.distributed.run set up
+        # BEFORE the model exists, so grad_scale = 1 / world and the parameter broadcast below are in effect from step one
+        rank, world, local = parallel.init()
+        max_batch = max(-(-cfg.DATALOADER.TRAIN_X.BATCH_SIZE // world), cfg.DATALOADER.TEST.BATCH_SIZE)
         self.model = CustomCLIP(shape, state, tokenized, ctx_token_ids=ctx_ids, max_batch=max_batch,
-                                dtype=PREC_TO_DTYPE[cc.PREC], device=f"cuda:{local}", seed=cfg.SEED, variant="cocoop")
+                                dtype=precision_to_dtype(cc.PREC), device=f"cuda:{local}", seed=cfg.SEED, variant="cocoop")
         print("Turning off gradients in both the image and the text encoder")  # structural: the module owns the 5 trainables only
         print(f"Parameters to be updated: {set(self.model.param_names)}")
         if cfg.MODEL.INIT_WEIGHTS:  # :234-235
@@ -70,22 +72,20 @@ class CoCoOp(TrainerX):
             parallel.broadcast_params(self.model.flat_params)
 
     def forward_backward(self, batch):
-        image, label = self.parse_batch_train(batch)
         # loss = model(image, label) (cross-entropy inside forward, :196-197) + backward in one library call
-        loss = self.model.forward_backward(image, label, grad_scale=parallel.grad_scale())
-        parallel.allreduce_grads(self.model.flat_grads)
-        self.optim.step()
-        loss_summary = {"loss": loss.item()}
-        if (self.batch_idx + 1) == self.num_batches:
-            self.update_lr()
-        return loss_summary
+        return data_parallel_step(self, batch)
 
     def parse_batch_train(self, batch):
         input = batch["img"]
         label = batch["label"]
+        input, label = parallel.shard_batch(input, label)  # N > 1: this rank's slice, as nn.DataParallel's scatter (:244-247)
         input = input.to(self.device)
         label = label.to(self.device)
         return input, label
+
+    def save_model(self, *args, **kwargs):
+        if parallel.is_main():
+            super().save_model(*args, **kwargs)
 
     def load_model(self, directory, epoch=None):
         if not directory:

@@ -295,8 +295,12 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
     float s = 0.f;
     for (int i = lane; i < C; i += 64) s += __expf(z[i] - m);
     s = wave_sum(s);
-    const int y = (int)labels[r];
-    if (lane == 0) row_loss[r] = (m + __logf(s)) - z[y];
+    // a label outside [0, C) (torch's F.cross_entropy asserts on it) must not become an out-of-bounds read: the row's loss
+    // is NaN, which the trainer's non-finite-loss check reports, and no one-hot is subtracted
+    const int64_t y64 = labels[r];
+    const bool y_ok = y64 >= 0 && y64 < (int64_t)C;
+    const int y = y_ok ? (int)y64 : -1;
+    if (lane == 0) row_loss[r] = y_ok ? (m + __logf(s)) - z[y] : __builtin_nanf("");
     if (dlogits) {
         const float is = 1.f / s;
         for (int i = lane; i < C; i += 64) dlogits[(size_t)r * C + i] = (__expf(z[i] - m) * is - (i == y ? 1.f : 0.f)) * gscale;

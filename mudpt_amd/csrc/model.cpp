@@ -1058,6 +1058,38 @@ extern "C" int mudpt_layernorm_bwd(int32_t dtype, const void* dy, int32_t lddy, 
     a.dres = dres; a.lddres = lddres; a.dx = dx; a.lddx = lddx; a.dx_lp = dx_lp; a.lddx_lp = lddx_lp; a.rows = rows; a.d = d;
     return launch_ln_bwd(dtype, a, (hipStream_t)stream);
 }
+extern "C" int mudpt_layernorm_fwd_fused(int32_t dtype, const float* x, int32_t ldx, const float* add, const void* add_lp, int32_t ldadd, const float* ov_rows,
+                                         int32_t ov_row0, int32_t ov_n, int32_t ov_L, float* xout, int32_t ldxout, const float* gamma, const float* beta, void* out,
+                                         int32_t ldo, int32_t out_f32, float* mean, float* rstd, int32_t rows, int32_t d, void* stream) {
+    LnFwdArgs a; a.x = x; a.ldx = ldx; a.add = add; a.add_lp = add_lp; a.ldadd = ldadd; a.xout = xout; a.ldxout = ldxout; a.gamma = gamma; a.beta = beta;
+    a.out = out; a.ldo = ldo; a.out_f32 = out_f32 != 0; a.mean = mean; a.rstd = rstd; a.rows = rows; a.d = d;
+    if (ov_rows) { a.ov_rows = ov_rows; a.ov_row0 = ov_row0; a.ov_n = ov_n; a.ov_L = ov_L; }
+    return launch_ln_fwd(dtype, a, (hipStream_t)stream);
+}
+extern "C" int mudpt_head(const float* img, const float* txt, const int64_t* labels, float scale, float grad_scale, int32_t B, int32_t C, int32_t e,
+                          float* logits, float* loss, float* dimg, float* dtxt, void* stream) {
+    ARG_CHECK(img && txt && logits && B > 0 && C > 0 && e > 0, "head: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    float* scratch = nullptr;
+    const size_t need = (size_t)B * e + (size_t)C * e + B + C + (size_t)B * C + B;
+    HIP_TRY(hipMalloc((void**)&scratch, need * 4));
+    HeadArgs h; h.img = img; h.txt = txt; h.labels = labels; h.scale = scale; h.logits = logits; h.loss = loss; h.dimg = dimg; h.dtxt = dtxt;
+    h.img_n = scratch; h.txt_n = h.img_n + (size_t)B * e; h.img_inv = h.txt_n + (size_t)C * e; h.txt_inv = h.img_inv + B;
+    h.dlogits = h.txt_inv + C; h.row_loss = h.dlogits + (size_t)B * C; h.grad_scale = grad_scale; h.B = B; h.C = C; h.e = e;
+    int rc = launch_head_fwd(h, s);
+    if (!rc && labels) rc = launch_head_bwd(h, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    return rc;
+}
+extern "C" int mudpt_reduce_rows(int32_t dtype, float* src, void* src_lp, int32_t B, int32_t L, int32_t d, int32_t row0, int32_t n, float* out,
+                                 int32_t zero_src, int32_t accumulate, float scale, void* stream) {
+    return launch_reduce_rows(dtype, src, src_lp, B, L, d, row0, n, out, zero_src != 0, accumulate != 0, scale, (hipStream_t)stream);
+}
+extern "C" int mudpt_sgemm(int32_t tA, int32_t tB, int32_t M, int32_t N, int32_t K, float alpha, const float* A, int32_t lda, const float* B, int32_t ldb,
+                           float beta, float* C, int32_t ldc, const float* bias, void* stream) {
+    return launch_sgemm(tA != 0, tB != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, (hipStream_t)stream);
+}
 extern "C" int mudpt_attention_padded_len(int32_t L) { return attn_padded_len(L); }
 extern "C" int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream) {
     AttnArgs a; a.qkv = qkv; a.out = out; a.lse = lse; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;

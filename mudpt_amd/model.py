@@ -136,6 +136,7 @@ class CustomCLIP(nn.Module):
         return "mudpt_prompt_learner.ctx" if self.variant == "mudpt" else "prompt_learner.ctx"
 
     def set_params(self, tensors: Dict[str, torch.Tensor]):
+        self._text_version = None
         with torch.no_grad():
             for k, p in self.named_parameters():
                 if k in tensors:
@@ -148,7 +149,24 @@ class CustomCLIP(nn.Module):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- trainers/mudpt.py:170-184 ---------------------------------------------------------------------------------
+    def _check_images(self, image: torch.Tensor):
+        S = self.shape.image_size
+        # the library is told only B: a wrong-sized batch would make the patch gather read out of bounds (trainers/mudpt.py:55 asserts
+        # the configured size; this asserts the data)
+        assert image.dim() == 4 and tuple(image.shape[1:]) == (3, S, S), f"images must be [B, 3, {S}, {S}], got {tuple(image.shape)}"
+        assert 0 < image.shape[0] <= self.max_batch, f"batch {image.shape[0]} outside 1..max_batch={self.max_batch}"
+
+    def invalidate_text_cache(self):
+        """Parameters changed behind the bucket's version counter (``p.data`` writes, optimizers, the library's SGD): the next eval
+        forward recomputes the text features."""
+        self._text_version = None
+
+    def load_state_dict(self, *args, **kwargs):
+        self._text_version = None
+        return super().load_state_dict(*args, **kwargs)
+
     def forward(self, image: torch.Tensor) -> torch.Tensor:
+        self._check_images(image)
         image = image.to(self.device, torch.float32).contiguous()
         B = image.shape[0]
         logits = torch.empty(B, self.n_cls, dtype=torch.float32, device=self.device)
@@ -163,6 +181,8 @@ class CustomCLIP(nn.Module):
     # -- trainers/mudpt.py:249-251 minus the optimizer step: loss (device scalar) + .grad of the 10 tensors ---------------
     def forward_backward(self, image: torch.Tensor, label: torch.Tensor, grad_scale: float = 1.0,
                          return_logits: bool = False):
+        self._check_images(image)
+        assert label.shape == (image.shape[0],), f"labels must be [B], got {tuple(label.shape)}"
         image = image.to(self.device, torch.float32).contiguous()
         label = label.to(self.device, torch.int64).contiguous()
         B = image.shape[0]

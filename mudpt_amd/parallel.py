@@ -28,6 +28,8 @@ def init(backend: str | None = None):
     rank, world, local = env_rank()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)  # RCCL binds the communicator to the current device
         dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
     return rank, world, local
 
@@ -35,6 +37,16 @@ def init(backend: str | None = None):
 def world_size() -> int:
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def is_main() -> bool:
+    """Rank 0 writes checkpoints and logs; every rank holds the same parameters after each step."""
+    return rank() == 0
 
 
 def grad_scale() -> float:
@@ -55,6 +67,32 @@ def broadcast_params(flat_params: torch.Tensor, src: int = 0) -> torch.Tensor:
         import torch.distributed as dist
         dist.broadcast(flat_params, src)
     return flat_params
+
+
+def shard_batch(image: torch.Tensor, label: torch.Tensor):
+    """This rank's contiguous slice of a global batch, as ``nn.DataParallel``'s scatter along dim 0 gives GPU k
+    (trainers/mudpt.py:230-233).  Dassl's loaders are not rank-aware: launched under torch.distributed.run every rank draws the
+    SAME global batch (equal seeds), so slicing it here reproduces the reference's split with no data-path collective.  A loader
+    that already yields per-rank batches (a DistributedSampler) opts out with MUDPT_DATA_SHARDED=1."""
+    w = world_size()
+    if w == 1 or os.environ.get("MUDPT_DATA_SHARDED") == "1":
+        return image, label
+    n = image.shape[0]
+    if n % w != 0:
+        raise ValueError(f"global batch {n} is not divisible by the {w} data-parallel ranks (equal shards are what makes the "
+                         "sum of 1/world-scaled local gradients the global-batch mean)")
+    idx = shard(n, rank(), w)
+    return image[idx.start:idx.stop], label[idx.start:idx.stop]
+
+
+def all_finite(loss: torch.Tensor, flat_grads: torch.Tensor) -> bool:
+    """Consensus form of Dassl's non-finite-loss check (``detect_anomaly``): a rank that raised alone would leave the others
+    hanging in the next collective, so the flag is reduced (MIN) and every rank takes the same branch."""
+    ok = (torch.isfinite(loss).all() & torch.isfinite(flat_grads).all()).to(torch.float32).reshape(1)
+    if world_size() > 1:
+        import torch.distributed as dist
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return bool(ok.item() > 0)
 
 
 def shard(n_items: int, rank: int, world: int) -> range:

@@ -64,6 +64,35 @@ def tokenize_prompts(prompts, ctx_len=77, near=None):
             raise RuntimeError(f"no BPE merge table available for prompt {e}: {no_vocab}") from None
 
 
+def data_parallel_step(trainer, batch):
+    """One training step of either plugin (trainers/mudpt.py:235-261, trainers/cocoop.py:246-276) in data-parallel form:
+    forward + cross-entropy + backward in ONE library call on this rank's images (gradient of loss / world), ONE all-reduce of the
+    flat bucket, the non-finite check on what every rank sees, then the optimizer step -- so replicas stay bitwise identical."""
+    image, label = trainer.parse_batch_train(batch)
+    loss = trainer.model.forward_backward(image, label, grad_scale=parallel.grad_scale())
+    parallel.allreduce_grads(trainer.model.flat_grads)
+    if not parallel.all_finite(loss, trainer.model.flat_grads):  # Dassl's model_backward_and_update checks the loss before backward
+        raise FloatingPointError("Loss is infinite or NaN!")
+    trainer.optim.step()
+    trainer.model.invalidate_text_cache()  # the optimizer wrote through .data views of the bucket
+    loss_summary = {"loss": loss.item()}  # the reference logs the local value too (trainers/mudpt.py:253-256)
+    if (trainer.batch_idx + 1) == trainer.num_batches:
+        trainer.update_lr()
+    return loss_summary
+
+
+def precision_to_dtype(prec: str) -> str:
+    """TRAINER.*.PREC -> MFMA operand type.  The reference's "fp32" (and, on its CPU path, "fp16": clip/clip.py:142-143 floats the
+    model) is a full fp32 model; this library has no fp32 matrix path for the towers: "fp32" runs the most accurate configuration it
+    has (fp16 operands with split text-tower operands, fp32 accumulate / residual / LayerNorm / softmax: logits within 1e-3 of fp32)
+    and says so instead of downgrading silently."""
+    if prec == "fp32":
+        import warnings
+        warnings.warn("TRAINER PREC='fp32': the MI355X path computes the towers with fp16 MFMA operands (fp32 accumulation, "
+                      "residual stream, LayerNorm and softmax); logits agree with an fp32 model to ~1e-3, not bit for bit", stacklevel=2)
+    return PREC_TO_DTYPE[prec]
+
+
 @TRAINER_REGISTRY.register()
 class MuDPT(TrainerX):
     def check_cfg(self, cfg):
@@ -102,10 +131,12 @@ class MuDPT(TrainerX):
         tokenized = tokenize_prompts(prompts, shape.ctx_len, near=cfg.MODEL.BACKBONE.PATH or None)
 
         print("Building custom CLIP")
-        rank, world, local = parallel.env_rank()
-        max_batch = max(cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.DATALOADER.TEST.BATCH_SIZE)
+        # one process per GPU (the reference: nn.DataParallel in one process): join the process group torch.distributed.run set up
+        # BEFORE the model exists, so grad_scale = 1 / world and the parameter broadcast below are in effect from step one
+        rank, world, local = parallel.init()
+        max_batch = max(-(-cfg.DATALOADER.TRAIN_X.BATCH_SIZE // world), cfg.DATALOADER.TEST.BATCH_SIZE)
         self.model = CustomCLIP(shape, state, tokenized, ctx_token_ids=ctx_ids, max_batch=max_batch,
-                                dtype=PREC_TO_DTYPE[mc.PREC], device=f"cuda:{local}", seed=cfg.SEED)
+                                dtype=precision_to_dtype(mc.PREC), device=f"cuda:{local}", seed=cfg.SEED)
         # the freeze rule of trainers/mudpt.py:205-218 is structural here: the module only owns the 10 trainables
         print(f"Parameters to be updated: {set(self.model.param_names)}")
         if cfg.MODEL.INIT_WEIGHTS:
@@ -122,23 +153,21 @@ class MuDPT(TrainerX):
             parallel.broadcast_params(self.model.flat_params)
 
     def forward_backward(self, batch):
-        image, label = self.parse_batch_train(batch)
-        # forward + F.cross_entropy + backward in one library call; .grad of the 10 tensors is written in place
-        loss = self.model.forward_backward(image, label, grad_scale=parallel.grad_scale())
-        parallel.allreduce_grads(self.model.flat_grads)
-        self.detect_anomaly(loss)  # Dassl's model_backward_and_update does this before backward
-        self.optim.step()
-        loss_summary = {"loss": loss.item()}
-        if (self.batch_idx + 1) == self.num_batches:
-            self.update_lr()
-        return loss_summary
+        return data_parallel_step(self, batch)
 
     def parse_batch_train(self, batch):
         input = batch["img"]
         label = batch["label"]
+        # N > 1: this rank's contiguous slice of the global batch, as nn.DataParallel's scatter (trainers/mudpt.py:230-233); the slice
+        # is taken on the host so only 1/world of the images crosses PCIe
+        input, label = parallel.shard_batch(input, label)
         input = input.to(self.device)
         label = label.to(self.device)
         return input, label
+
+    def save_model(self, *args, **kwargs):
+        if parallel.is_main():  # replicas are identical: one writer per OUTPUT_DIR
+            super().save_model(*args, **kwargs)
 
     def load_model(self, directory, epoch=None):
         if not directory:

@@ -4,6 +4,7 @@ Run in the build container only (needs /root/reference, which never travels to t
 
     python tests/golden/gen_golden.py            # writes tests/golden/*.npz
     python tests/golden/gen_golden.py --cocoop-only   # only the CoCoOp fixtures (trainers/cocoop.py)
+    python tests/golden/gen_golden.py --many-only     # only the 208-class fixture (BASELINE configs[2]'s text-heavy shape)
 
 What runs: ``clip.model.CLIP`` and ``trainers.mudpt.CustomCLIP`` imported unmodified from
 /root/reference; their parameters are overwritten with the seeded recipe of
@@ -94,8 +95,32 @@ def seeded_images(cfg: O.Config, batch: int, seed: int) -> torch.Tensor:
     return torch.randn(batch, 3, cfg.image_size, cfg.image_size, generator=g)
 
 
+# Word pool for the many-class fixture (ImageNet-style names): k-word names give class prompts of mixed token length, so the
+# EOT positions spread over 7..17 of the 77 and the trimmed text tower runs Le > 9 with a different row count per class.
+WORDS = ["tench", "goldfish", "shark", "hammerhead", "stingray", "rooster", "ostrich", "brambling", "goldfinch", "junco",
+         "bunting", "robin", "bulbul", "jay", "magpie", "chickadee", "ouzel", "kite", "eagle", "vulture", "owl", "salamander",
+         "newt", "axolotl", "bullfrog", "loggerhead", "terrapin", "iguana", "chameleon", "agama", "alligator", "triceratops",
+         "thunder", "ringneck", "hognose", "vine", "night", "boa", "python", "cobra", "mamba", "rattlesnake", "sidewinder",
+         "trilobite", "harvestman", "scorpion", "garden", "barn", "wolf", "tick", "centipede", "grouse", "ptarmigan", "prairie",
+         "peacock", "quail", "partridge", "macaw", "cockatoo", "lorikeet", "coucal", "hornbill", "hummingbird", "toucan"]
+
+
+def many_classnames(n: int = 208):
+    """n distinct names of 1..9 pool words (deterministic): 'tench', 'goldfish shark', ... -- mixed BPE lengths."""
+    names, k, i = [], 1, 0
+    while len(names) < n:
+        ws = [WORDS[(i + 7 * j * (k + 1)) % len(WORDS)] for j in range(k)]
+        nm = " ".join(ws)
+        if nm not in names:
+            names.append(nm)
+        i += 1
+        k = 1 + (i * 5 + i // 3) % 9
+    return names
+
+
 def run(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, train_seed: int,
-        image_seed: int, sample_big: bool):
+        image_seed: int, sample_big: bool, classnames=None, taps_wanted: bool = True):
+    CLASSNAMES = classnames or globals()["CLASSNAMES"]
     clip, cm, mudpt, CN = import_reference()
     ycfg = CN(TRAINER=CN(NAME="MuDPT", MUDPT=CN(N_CTX=cfg.n_ctx, CTX_INIT=ctx_init,
                                                  DEEP_PROMPT_DEPTH=cfg.depth, PREC="fp32")),
@@ -129,13 +154,14 @@ def run(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, t
             taps[key] = out[0].detach().permute(1, 0, 2).contiguous()  # LND -> NLD
         return fn
 
-    for i, blk in enumerate(model.image_encoder.transformer.resblocks):
-        blk.register_forward_hook(hook(f"visual.transformer.resblocks.{i}.out"))
-    for i, blk in enumerate(model.text_encoder.transformer.resblocks):
-        blk.register_forward_hook(hook(f"transformer.resblocks.{i}.out"))
+    if taps_wanted:
+        for i, blk in enumerate(model.image_encoder.transformer.resblocks):
+            blk.register_forward_hook(hook(f"visual.transformer.resblocks.{i}.out"))
+        for i, blk in enumerate(model.text_encoder.transformer.resblocks):
+            blk.register_forward_hook(hook(f"transformer.resblocks.{i}.out"))
 
     images = seeded_images(cfg, batch, image_seed)
-    labels = torch.arange(batch) * 3 % len(CLASSNAMES)
+    labels = torch.arange(batch) * 3 % len(CLASSNAMES) if classnames is None else (torch.arange(batch) * 101 + 17) % len(CLASSNAMES)
     model.train()
     logits = model(images)
     loss = torch.nn.functional.cross_entropy(logits, labels)
@@ -254,6 +280,11 @@ if __name__ == "__main__":
     if "--tokenizer-only" in sys.argv:
         run_tokenizer()
         sys.exit(0)
+    if "--many-only" in sys.argv:
+        # BASELINE configs[2]'s shape of work at fixture size: ViT-B/16, 208 class prompts of mixed length (EOT 7..17), B = 2
+        run(O.VIT_B16, "mudpt_vitb16_c208_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=3, image_seed=2468,
+            sample_big=True, classnames=many_classnames(208), taps_wanted=False)
+        sys.exit(0)
     if "--vitl-only" in sys.argv:
         run(O.VIT_L14_336, "mudpt_vitl14_336_b1", "a photo of a", batch=1, frozen_seed=5, train_seed=6, image_seed=77, sample_big=True)
         sys.exit(0)
@@ -265,6 +296,8 @@ if __name__ == "__main__":
     run(O.VIT_B16, "mudpt_vitb16_b4", "a photo of a", batch=4, frozen_seed=0, train_seed=1, image_seed=1234,
         sample_big=True)
     run(O.VIT_L14_336, "mudpt_vitl14_336_b1", "a photo of a", batch=1, frozen_seed=5, train_seed=6, image_seed=77, sample_big=True)
+    run(O.VIT_B16, "mudpt_vitb16_c208_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=3, image_seed=2468,
+        sample_big=True, classnames=many_classnames(208), taps_wanted=False)
     run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
     run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)
     run_tokenizer()

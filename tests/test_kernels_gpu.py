@@ -168,22 +168,139 @@ def test_layernorm_fwd_bwd(lib, dtype, rows, d):
     torch.testing.assert_close(dx_lp.cpu().float(), dx_ref + dres, atol=4 * EPS[dtype] * 4, rtol=4 * EPS[dtype])
 
 
-def test_layernorm_fused_add_and_prompt_splice():
-    """LN forward with the residual add and the deep-prompt splice fused in (what block_fwd uses): rows outside the
-    prompt range are x + add, prompt rows are REPLACED by the given rows; the block input is written back."""
-    from mudpt_amd import capi
-    import ctypes
-    lib = capi.load()
-    # not exported as a single-kernel entry point with these extras: exercised through a tiny model forward instead
-    # (tests/test_model_gpu.py::test_block_outputs_match_reference_fp16 compares every block's input and output);
-    # here: the plain kernel must be unaffected by the new arguments being absent.
-    d, rows = 256, 9
-    x = torch.randn(rows, d).cuda()
-    g, b = torch.ones(d).cuda(), torch.zeros(d).cuda()
-    out = torch.empty(rows, d, device="cuda")
-    ok(lib, lib.mudpt_layernorm_fwd(0, P(x), d, None, P(g), P(b), P(out), d, 1, None, None, rows, d, None))
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("add_kind", ["f32", "lp", "none"])
+def test_layernorm_fused_add_and_prompt_splice(lib, dtype, add_kind):
+    """What block_fwd fuses into LayerNorm (clip/model.py:281-301): v = x + add (fp32 addend, or the T-precision update stream),
+    rows 1..n of every L-row sequence REPLACED by the deep-prompt rows (no add on those), v written back as the block input
+    (bit-exact: one fp32 add), then normalised."""
+    dt, tt = DT[dtype]
+    nseq, L, d, row0, n = 5, 13, 512, 9, 4   # vision-style: the last n rows of every sequence
+    rows = nseq * L
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(rows, d, generator=g) * 1.5 + 0.3
+    add = torch.randn(rows, d, generator=g) * 0.5
+    add_t = add.to(tt)
+    ov = torch.randn(n, d, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    v = x + (add if add_kind == "f32" else add_t.float() if add_kind == "lp" else 0)
+    v = v.view(nseq, L, d).clone()
+    v[:, row0:row0 + n] = ov
+    v = v.view(rows, d)
+    y = O.layer_norm(v, gamma, beta)
+    xc, gc, bc, oc = x.cuda(), gamma.cuda(), beta.cuda(), ov.cuda()
+    a32 = add.cuda() if add_kind == "f32" else None
+    alp = add_t.cuda() if add_kind == "lp" else None
+    xout = torch.full((rows, d), float("nan"), device="cuda")
+    out = torch.empty(rows, d, device="cuda", dtype=tt)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ok(lib, lib.mudpt_layernorm_fwd_fused(dt, P(xc), d, P(a32), P(alp), d, P(oc), row0, n, L, P(xout), d, P(gc), P(bc), P(out), d, 0,
+                                          P(mean), P(rstd), rows, d, None))
     torch.cuda.synchronize()
-    torch.testing.assert_close(out.cpu(), torch.nn.functional.layer_norm(x.cpu(), (d,)), atol=2e-5, rtol=1e-5)
+    assert torch.equal(xout.cpu(), v)                      # the saved block input: exact
+    torch.testing.assert_close(out.cpu().float(), y, atol=4 * EPS[dtype], rtol=4 * EPS[dtype])
+    torch.testing.assert_close(mean.cpu(), v.mean(-1), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(rstd.cpu(), (v.var(-1, unbiased=False) + 1e-5).rsqrt(), atol=1e-5, rtol=2e-5)
+    # fp32 output and no splice: every row is x + add
+    o32 = torch.empty(rows, d, device="cuda")
+    ok(lib, lib.mudpt_layernorm_fwd_fused(dt, P(xc), d, P(a32), P(alp), d, None, 0, 0, 1, None, 0, P(gc), P(bc), P(o32), d, 1, None, None, rows, d, None))
+    torch.cuda.synchronize()
+    v2 = x + (add if add_kind == "f32" else add_t.float() if add_kind == "lp" else 0)
+    torch.testing.assert_close(o32.cpu(), O.layer_norm(v2, gamma, beta), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,e", [(4, 11, 512), (256, 1000, 512), (5, 3, 128), (3, 1, 64)])
+def test_head_matches_torch_cross_entropy(lib, B, C, e):
+    """Cosine logits + mean cross-entropy, forward and backward (trainers/mudpt.py:178-182,250) against torch autograd in float64,
+    at the benchmark's C = 11 and at BASELINE configs[2]'s C = 1000 (CE over 1000 columns)."""
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    img, txt = torch.randn(B, e, generator=g) * 3, torch.randn(C, e, generator=g) * 0.2
+    labels = torch.randint(0, C, (B,), generator=g)
+    scale, gscale = 14.2857, 0.5
+    i64, t64 = img.double().requires_grad_(True), txt.double().requires_grad_(True)
+    ref_logits = scale * torch.nn.functional.normalize(i64, dim=-1) @ torch.nn.functional.normalize(t64, dim=-1).t()
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, labels)
+    (gscale * ref_loss).backward()
+    ic, tc, lc = img.cuda(), txt.cuda(), labels.cuda()
+    logits, loss = torch.empty(B, C, device="cuda"), torch.empty(1, device="cuda")
+    dimg, dtxt = torch.empty(B, e, device="cuda"), torch.empty(C, e, device="cuda")
+    ok(lib, lib.mudpt_head(P(ic), P(tc), P(lc), scale, gscale, B, C, e, P(logits), P(loss), P(dimg), P(dtxt), None))
+    torch.testing.assert_close(logits.cpu().double(), ref_logits.detach(), atol=2e-5, rtol=1e-5)
+    assert abs(loss.item() - ref_loss.item()) <= 2e-6 * max(1.0, abs(ref_loss.item()))
+    for got, ref in ((dimg, i64.grad), (dtxt, t64.grad)):
+        rms = ref.pow(2).mean().sqrt().item()
+        assert (got.cpu().double() - ref).abs().max().item() <= 2e-5 * rms + 1e-12
+    # forward only (model_inference): no labels
+    logits2 = torch.empty(B, C, device="cuda")
+    ok(lib, lib.mudpt_head(P(ic), P(tc), None, scale, 1.0, B, C, e, P(logits2), None, None, None, None))
+    assert torch.equal(logits2, logits)
+
+
+def test_head_label_out_of_range_gives_nan_loss_not_a_fault(lib):
+    B, C, e = 4, 7, 64
+    img, txt = torch.randn(B, e).cuda(), torch.randn(C, e).cuda()
+    labels = torch.tensor([0, 7, 3, -1]).cuda()  # 7 and -1 are outside [0, C)
+    logits, loss = torch.empty(B, C, device="cuda"), torch.empty(1, device="cuda")
+    dimg, dtxt = torch.empty(B, e, device="cuda"), torch.empty(C, e, device="cuda")
+    ok(lib, lib.mudpt_head(P(img), P(txt), P(labels), 10.0, 1.0, B, C, e, P(logits), P(loss), P(dimg), P(dtxt), None))
+    assert torch.isnan(loss).all() and torch.isfinite(logits).all()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,L,d,row0,n", [(256, 201, 768, 197, 4), (1000, 20, 512, 1, 4), (3, 7, 64, 2, 1), (33, 5, 128, 0, 2)])
+def test_reduce_rows(lib, dtype, B, L, d, row0, n):
+    """Backward of the prompt splice: sum over the batch of the n prompt rows.  Against a float64 sum, bit for bit run to run,
+    from the fp32 stream and from its T copy, with accumulate and with clearing of the summed rows."""
+    dt, tt = DT[dtype]
+    g = torch.Generator().manual_seed(B + d)
+    src = torch.randn(B, L, d, generator=g)
+    ref = src[:, row0:row0 + n].double().sum(0)
+    sc = src.cuda()
+    out = torch.empty(n, d, device="cuda")
+    ok(lib, lib.mudpt_reduce_rows(dt, P(sc), None, B, L, d, row0, n, P(out), 0, 0, 0.25, None))
+    torch.cuda.synchronize()
+    tol = 4e-6 * B ** 0.5  # fp32 summation of B unit-variance values: a few ulp of sqrt(B)
+    assert (out.cpu().double() - 0.25 * ref).abs().max().item() <= tol
+    again = torch.empty(n, d, device="cuda")
+    for _ in range(3):
+        ok(lib, lib.mudpt_reduce_rows(dt, P(sc), None, B, L, d, row0, n, P(again), 0, 0, 0.25, None))
+        torch.cuda.synchronize()
+        assert torch.equal(again, out)   # fixed-order tree: bitwise reproducible
+    # accumulate: out += sum
+    ok(lib, lib.mudpt_reduce_rows(dt, P(sc), None, B, L, d, row0, n, P(again), 0, 1, 0.25, None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(again, 2 * out, atol=1e-6, rtol=1e-6)
+    # T-precision source (the bf16 gradient stream), cleared afterwards together with the fp32 copy
+    lp = src.to(tt).cuda()
+    ref_lp = lp.cpu().float()[:, row0:row0 + n].double().sum(0)
+    out2 = torch.empty(n, d, device="cuda")
+    ok(lib, lib.mudpt_reduce_rows(dt, None, P(lp), B, L, d, row0, n, P(out2), 1, 0, 1.0, None))
+    torch.cuda.synchronize()
+    assert (out2.cpu().double() - ref_lp).abs().max().item() <= tol
+    assert torch.count_nonzero(lp[:, row0:row0 + n]) == 0
+    keep = torch.ones(L, dtype=torch.bool); keep[row0:row0 + n] = False
+    assert torch.equal(lp[:, keep.cuda()].cpu(), src.to(tt)[:, keep])  # other rows untouched
+
+
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(4, 768, 512), (44, 512, 768), (17, 33, 70), (256, 11, 512)])
+def test_sgemm_all_transpose_forms(lib, tA, tB, M, N, K):
+    """fp32 C = alpha op(A) op(B) + bias + beta C: the prompt projections (trainers/mudpt.py:127-128, clip/model.py:539), their
+    weight / input gradients and the logit contraction; every transpose form, ragged shapes."""
+    g = torch.Generator().manual_seed(M * N + K + 2 * tA + tB)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((N, K) if tB else (K, N), generator=g)
+    bias, C0 = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    opA, opB = (A.t() if tA else A).double(), (B.t() if tB else B).double()
+    ref = 0.7 * (opA @ opB) + bias.double() + 0.3 * C0.double()
+    Ac, Bc, bc, Cc = A.cuda(), B.cuda(), bias.cuda(), C0.clone().cuda()
+    ok(lib, lib.mudpt_sgemm(tA, tB, M, N, K, 0.7, P(Ac), A.stride(0), P(Bc), B.stride(0), 0.3, P(Cc), N, P(bc), None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(Cc.cpu().double(), ref, atol=3e-5 * K ** 0.5, rtol=1e-5)
+    Cd = torch.full((M, N), float("nan"), device="cuda")   # beta = 0 must not read C
+    ok(lib, lib.mudpt_sgemm(tA, tB, M, N, K, 1.0, P(Ac), A.stride(0), P(Bc), B.stride(0), 0.0, P(Cd), N, None, None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(Cd.cpu().double(), opA @ opB, atol=3e-5 * K ** 0.5, rtol=1e-5)
 
 
 def test_layernorm_gather_scatter(lib):

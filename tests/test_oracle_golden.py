@@ -32,6 +32,14 @@ def test_forward_backward_matches_reference(case):
             torch.testing.assert_close(g[::8, ::8], sample, atol=1e-3 * scale + 1e-9, rtol=1e-4)
 
 
+def test_many_class_fixture_matches_reference():
+    """208 class prompts of mixed length (EOT 7..25), B = 2: the shape of work of BASELINE configs[2] (C = 1000) at fixture size."""
+    c = GoldenCase("mudpt_vitb16_c208_b2")
+    c.check_recipe()
+    assert c.tokens.shape == (208, 77) and int(c.eot.min()) == 7 and int(c.eot.max()) >= 16 and len(set(c.eot.tolist())) >= 10
+    test_forward_backward_matches_reference(c)
+
+
 def test_block_outputs_match_reference(case):
     taps = {}
     with torch.no_grad():

@@ -61,6 +61,100 @@ def test_two_rank_gradient_equals_global_batch(tmp_path):
     assert torch.equal(r0["params"], r1["params"])  # replicas stay bitwise identical after the step
 
 
+class _OracleModel(torch.nn.Module):
+    """Stands in for mudpt_amd.model.CustomCLIP on CPU: same surface (flat buckets, named views, forward_backward writing
+    grad_scale * gradient into the bucket), arithmetic by the oracle.  What is under test is the PLUGIN's step, not the library."""
+
+    def __init__(self, case, params):
+        super().__init__()
+        self.case = case
+        self.flat_params = O.flatten(params).clone()
+        self.flat_grads = torch.zeros_like(self.flat_params)
+        off = 0
+        self.views = {}
+        for k in O.TRAINABLE_ORDER:
+            n = params[k].numel()
+            p = torch.nn.Parameter(self.flat_params[off:off + n].view_as(params[k]))
+            p.grad = self.flat_grads[off:off + n].view_as(params[k])
+            self.register_parameter(k.replace(".", "__"), p)
+            off += n
+        self.calls = []
+
+    def forward_backward(self, image, label, grad_scale=1.0):
+        c = self.case
+        self.calls.append((tuple(image.shape), float(grad_scale)))
+        loss, _, grads = O.forward_backward(c.cfg, c.frozen, O.unflatten(self.flat_params.clone(), c.cfg), c.class_embedding, c.eot, image, label)
+        self.flat_grads.copy_(O.flatten(grads) * grad_scale)
+        return loss.detach()
+
+    def invalidate_text_cache(self):
+        pass
+
+
+def _plugin_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from mudpt_amd import parallel, trainer
+    parallel.init("gloo")
+    case = GoldenCase("mudpt_tiny")
+    g = torch.Generator().manual_seed(123)
+    B = 4  # the GLOBAL batch every rank's (rank-unaware) loader yields; the plugin slices it
+    batches = [{"img": torch.randn(B, 3, case.cfg.image_size, case.cfg.image_size, generator=g), "label": torch.randint(0, 11, (B,), generator=g)}
+               for _ in range(2)]
+    t = object.__new__(trainer.MuDPT)
+    t.model = _OracleModel(case, case.params)
+    t.optim = torch.optim.SGD(t.model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    t.device, t.batch_idx, t.num_batches = torch.device("cpu"), 0, 99
+    losses = [t.forward_backward(b)["loss"] for b in batches]
+    assert t.model.calls == [((B // world, 3, case.cfg.image_size, case.cfg.image_size), 1.0 / world)] * 2, t.model.calls
+    # a non-finite loss on ONE rank must stop every rank (no hang in the next collective)
+    bad = torch.tensor(float("nan") if rank == 1 else 1.0)
+    assert parallel.all_finite(bad, t.model.flat_grads) is False
+    torch.save({"params": t.model.flat_params.clone(), "losses": losses}, f"{out}.r{rank}")
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_plugin_step_is_data_parallel_at_world_2(tmp_path):
+    """The trainer plugin's own step under torch.distributed (gloo, 2 ranks): the process group exists, each rank takes its slice of
+    the loader's global batch (nn.DataParallel's scatter, trainers/mudpt.py:230-233), gradients are all-reduced BEFORE optim.step,
+    replicas are bitwise identical after two momentum-SGD steps and equal the single-process run on the whole batches."""
+    from mudpt_amd import trainer
+    out = str(tmp_path / "plugin")
+    mp.spawn(_plugin_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".r0"), torch.load(out + ".r1")
+    assert torch.equal(r0["params"], r1["params"])
+    # single process, same two global batches
+    case = GoldenCase("mudpt_tiny")
+    g = torch.Generator().manual_seed(123)
+    t = object.__new__(trainer.MuDPT)
+    t.model = _OracleModel(case, case.params)
+    t.optim = torch.optim.SGD(t.model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    t.device, t.batch_idx, t.num_batches = torch.device("cpu"), 0, 99
+    for _ in range(2):
+        t.forward_backward({"img": torch.randn(4, 3, case.cfg.image_size, case.cfg.image_size, generator=g), "label": torch.randint(0, 11, (4,), generator=g)})
+    assert t.model.calls[0][1] == 1.0
+    torch.testing.assert_close(r0["params"], t.model.flat_params, atol=2e-6, rtol=1e-5)
+    moved = (t.model.flat_params - O.flatten(case.params)).abs().max().item()
+    assert moved > 1e-4  # the steps did something
+
+
+def test_shard_batch_requires_divisible_global_batch(monkeypatch):
+    from mudpt_amd import parallel
+    x, y = torch.zeros(5, 3, 2, 2), torch.zeros(5, dtype=torch.long)
+    assert parallel.shard_batch(x, y)[0] is x  # single process: untouched
+    monkeypatch.setattr(parallel, "world_size", lambda: 2)
+    monkeypatch.setattr(parallel, "rank", lambda: 1)
+    with pytest.raises(ValueError, match="not divisible"):
+        parallel.shard_batch(x, y)
+    a, b = parallel.shard_batch(x[:4], y[:4])
+    assert a.shape[0] == 2 and a.data_ptr() == x[2:4].data_ptr()
+    monkeypatch.setenv("MUDPT_DATA_SHARDED", "1")   # a rank-aware loader opts out
+    assert parallel.shard_batch(x, y)[0] is x
+
+
 def test_single_process_is_a_noop():
     from mudpt_amd import parallel
     t = torch.arange(5.0)
