@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
-    ap.add_argument("--gemm-variant", type=int, default=0, help="tuning knob passed to mudpt_debug_set (A/B runs on one box)")
+    ap.add_argument("--gemm-variant", type=int, default=0, help="tuning knob passed to mudpt_model_set (A/B runs on one box)")
     ap.add_argument("--fp32-streams", action="store_true", help="keep the update / gradient streams in fp32 (A/B of the bf16 streams)")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a captured hipGraph (implies --no-profile)")
     args = ap.parse_args()
@@ -97,17 +97,18 @@ def main():
 
     from mudpt_amd.model import CustomCLIP, ModelShape
     from mudpt_amd import synth, capi
+    knobs = {}
     if args.gemm_variant:
-        capi.check(capi.load().mudpt_debug_set(b"gemm_variant", args.gemm_variant))
+        knobs["gemm_variant"] = args.gemm_variant
     if args.fp32_streams:
-        capi.check(capi.load().mudpt_debug_set(b"lp_grad", 0))
+        knobs["lp_grad"] = 0
     shape = ModelShape()  # CLIP ViT-B/16, n_ctx 4, depth 12
     if args.arch == "vit_l14_336":
         shape = ModelShape(image_size=336, patch=14, v_width=1024, v_layers=24, v_heads=16, t_width=768, t_layers=12, t_heads=12, embed_dim=768, n_ctx=4, depth=24)
     B, C = args.batch, args.classes
     tok = synth.bench_tokenized_prompts() if C == 11 else synth.synthetic_tokenized_prompts(C)
     model = CustomCLIP(shape, synth.random_clip_state(shape, seed=0), tok, ctx_token_ids=synth.CTX_INIT_TOKENS,
-                       max_batch=B, dtype=args.dtype, device=f"cuda:{local}", seed=1)  # same seeds on every rank: replicas
+                       max_batch=B, dtype=args.dtype, device=f"cuda:{local}", seed=1, knobs=knobs)  # same seeds on every rank: replicas
     g = torch.Generator().manual_seed(1234 + rank)
     images = torch.randn(B, 3, shape.image_size, shape.image_size, generator=g).cuda()
     labels = torch.randint(0, C, (B,), generator=g).cuda()

@@ -11,6 +11,7 @@
  *   mudpt_forward                        trainers/mudpt.py:170-184 CustomCLIP.forward == model_inference()
  *   mudpt_forward_backward               trainers/mudpt.py:249-251 forward, F.cross_entropy, backward
  *   mudpt_sgd_step                       trainers/mudpt.py:251     model_backward_and_update's optimizer step
+ *   mudpt_allreduce_grads                trainers/mudpt.py:230-233 nn.DataParallel's gradient reduce (here: one RCCL all-reduce)
  *   mudpt_gemm / _layernorm_* / _attention_*   the ATen ops under clip/model.py:164-175,257-301 (unit parity)
  * With mudpt_config.variant = MUDPT_VARIANT_COCOOP the same entry points run the CoCoOp path (trainers/cocoop.py):
  *   mudpt_create / mudpt_set_weight      trainers/cocoop.py:22-40  load_clip_to_cpu: vanilla CLIP (clip/model.py:443-496 ViT)
@@ -101,6 +102,13 @@ int mudpt_forward_ex(mudpt_model* m, const float* images_dev, int32_t batch, flo
 int mudpt_forward_backward(mudpt_model* m, const float* images_dev, const int64_t* labels_dev, int32_t batch,
                            float grad_scale, float* loss_dev, float* logits_dev, void* stream);
 
+/* Data parallelism (replaces nn.DataParallel, trainers/mudpt.py:230-233): one process per GPU, each computing the gradient of
+ * (1/world) * local-mean loss (grad_scale above); the ONE exchange of a step is the sum of the flat gradient bucket over the ranks.
+ * A host with torch.distributed does that itself (mudpt_amd/parallel.py: dist.all_reduce on the bound bucket); any other host
+ * passes its RCCL communicator (ncclComm_t as void*, created with ncclCommInitRank) here.  In place on the bound bucket, asynchronous
+ * on `stream`; RCCL is resolved from the process at first use (no link-time dependency). */
+int mudpt_allreduce_grads(mudpt_model* m, void* nccl_comm, void* stream);
+
 /* Static loss scale of the backward pass (default 128): per-sample logit gradients are multiplied by it so the
  * fp16 copies of the token gradients stay normal; the gradients written to the bucket are unscaled again.
  * The reference's analogue is GradScaler under PREC == "amp" (trainers/mudpt.py:228,243-246). */
@@ -117,9 +125,11 @@ int mudpt_sgd_reset(mudpt_model* m);
  * block runs on those rows only), "image_features", "text_features".  host_out may be NULL to query *numel. */
 int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* host_out, size_t capacity, size_t* numel);
 
-/* Tuning knobs for A/B measurements in one process (tools/gemm_bench.py, tests): "gemm_variant", "lp_grad", "txt_split",
- * "txt_trim" (0 = run the text tower on all ctx_len positions; read by the next mudpt_set_class_prompts). */
-int mudpt_debug_set(const char* name, int32_t value);
+/* Per-handle tuning knobs for A/B measurements in one process (tools/gemm_bench.py, tests); nothing is process-global, so two
+ * models in one process do not interfere: "gemm_variant"; "lp_grad" (bf16 mode: 0 keeps the gradient / update streams in fp32);
+ * "txt_split" (fp16 mode: 0 = no split operands in the text tower; only before the first mudpt_set_weight); "txt_trim"
+ * (0 = run the text tower on all ctx_len positions; read by the next mudpt_set_class_prompts, which must follow). */
+int mudpt_model_set(mudpt_model* m, const char* name, int32_t value);
 
 /* Measurement hook (bench.py): bracket every MFMA GEMM launch of the path with HIP events on its launch stream.
  * mudpt_profile_read synchronises and returns the summed duration, the summed algorithmic FLOPs (2 M N K) and
@@ -132,7 +142,8 @@ int mudpt_profile_read(mudpt_model* m, double* gemm_ms, double* gemm_flop, int64
  *            3 out0 = acc * QuickGELU'(aux) | 4 patch-embed scatter + pos | 5 store f32 */
 int mudpt_gemm(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda,
                const void* B, int32_t ldb, const float* bias, void* out0, int32_t ldo0, void* out1, int32_t ldo1,
-               const void* aux, int32_t ldaux, int32_t patches, int32_t seq_len, const float* pos, void* stream);
+               const void* aux, int32_t ldaux, int32_t patches, int32_t seq_len, const float* pos, int32_t variant, void* stream);
+/* variant: kernel-choice knob for tests / tuning (0 = the default dispatch). */
 int mudpt_layernorm_fwd(int32_t dtype, const float* x, int32_t ldx, const int32_t* row_index, const float* gamma,
                         const float* beta, void* out, int32_t ldo, int32_t out_f32, float* mean, float* rstd,
                         int32_t rows, int32_t d, void* stream);

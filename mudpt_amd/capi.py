@@ -45,13 +45,14 @@ SIGNATURES = {
     "mudpt_forward_backward": (_i32, [_vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "mudpt_sgd_step": (_i32, [_vp, _f32, _f32, _f32, _f32, _i32, _vp]),
     "mudpt_sgd_reset": (_i32, [_vp]),
+    "mudpt_allreduce_grads": (_i32, [_vp, _vp, _vp]),
     "mudpt_debug_read": (_i32, [_vp, C.c_char_p, _i32, _vp, _sz, C.POINTER(_sz)]),
     "mudpt_set_loss_scale": (_i32, [_vp, _f32]),
-    "mudpt_debug_set": (_i32, [C.c_char_p, _i32]),
+    "mudpt_model_set": (_i32, [_vp, C.c_char_p, _i32]),
     "mudpt_profile_enable": (_i32, [_vp, _i32]),
     "mudpt_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mudpt_gemm": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32,
-                          _i32, _i32, _vp, _vp]),
+                          _i32, _i32, _vp, _i32, _vp]),
     "mudpt_layernorm_fwd": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "mudpt_layernorm_bwd": (_i32, [_i32, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
                                    _i32, _i32, _i32, _vp]),

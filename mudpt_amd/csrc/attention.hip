@@ -781,8 +781,9 @@ template <typename T, int NC, bool CAUSAL>
 static int fwd_pair_cfg(const AttnArgs& a, hipStream_t s) {
     constexpr int lds = 2 * NC * 32 * RS * 2 + NC * 32 * 4;
     auto kern = attn_fwd_pair_kernel<T, NC, CAUSAL>;
-    static bool once = false;
-    if (!once) { if (int e = set_lds(kern, lds)) return e; once = true; }
+    static PerDevice pd;
+    const int dev = current_device();
+    if (!pd.done[dev]) { if (int e = set_lds(kern, lds)) return e; pd.done[dev] = true; }
     hipLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(NC * 64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
@@ -793,15 +794,14 @@ static int fwd_cfg(const AttnArgs& a, hipStream_t s) {
     if constexpr (CAUSAL) return fwd_pair_cfg<T, NC, CAUSAL>(a, s);
     constexpr int lds = 4 * NC * 32 * 128 + NC * 32 * 4;  // two (K, V) image pairs + the key mask
     auto kern = attn_fwd_kernel<T, NC, CAUSAL>;
-    static bool once = false;
-    static int ncu = 0;
-    if (!once) {
+    static PerDevice pd;
+    const int dev = current_device();
+    if (!pd.done[dev]) {
         if (int e = set_lds(kern, lds)) return e;
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        once = true;
+        HIP_TRY(hipDeviceGetAttribute(&pd.ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+        pd.done[dev] = true;
     }
+    const int ncu = pd.ncu[dev];
     const int npairs = a.B * a.H, per_cu = 163840 / lds > 0 ? 163840 / lds : 1;
     const int cap = ncu * (per_cu * 2 * NC <= 32 ? per_cu : 32 / (2 * NC));  // resident workgroups: LDS and the 32-wave limit
     hipLaunchKernelGGL(kern, dim3(npairs < cap ? npairs : cap), dim3(NC * 128), lds, s, a, npairs);
@@ -815,11 +815,12 @@ static int bwd_cfg(const AttnArgs& a, hipStream_t s) {
     constexpr int lds2 = 2 * NC * 32 * RS * 2 + 2 * NC * 32 * 4;
     auto k1 = attn_bwd_dq_kernel<T, NC, CAUSAL>;
     auto k2 = attn_bwd_dkv_kernel<T, NC, CAUSAL>;
-    static bool once = false;
-    if (!once) {
+    static PerDevice pd;
+    const int dev = current_device();
+    if (!pd.done[dev]) {
         if (int e = set_lds(k1, lds1)) return e;
         if (int e = set_lds(k2, lds2)) return e;
-        once = true;
+        pd.done[dev] = true;
     }
     hipLaunchKernelGGL(k1, dim3(a.B * a.H), dim3(NC * 64), lds1, s, a, (const void*)a.out);
     hipLaunchKernelGGL(k2, dim3(a.B * a.H), dim3(NC * 64), lds2, s, a);

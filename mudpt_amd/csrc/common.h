@@ -78,6 +78,19 @@ namespace mudpt {
 void set_error(const char* fmt, ...);
 }
 
+namespace mudpt {
+// One-time-per-DEVICE launch setup (function attributes and CU counts belong to a device; one process may drive several GPUs).
+struct PerDevice {
+    bool done[64] = {};
+    int ncu[64] = {};
+};
+inline int current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 63;
+}
+}  // namespace mudpt
+
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
         hipError_t _e = (expr);                                                             \

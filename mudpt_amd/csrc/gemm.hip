@@ -179,10 +179,11 @@ template <typename T, int BM, int BN, int WM, int WN, int EPI, int NS = 2>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int lds = NS * (BM + BN) * 64 * 2;
     auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, NS>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice pd;
+    const int dev = current_device();
+    if (!pd.done[dev]) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        pd.done[dev] = true;
     }
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, a);
@@ -190,14 +191,13 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return MUDPT_OK;
 }
 
-int g_gemm_variant = 0;  // tuning knob (mudpt_debug_set "gemm_variant"): 0 = default kernel choice, 1/2/4 = force a simple tile
-
+// variant: tuning knob (mudpt_model_set "gemm_variant" / mudpt_gemm's last argument): 0 = default kernel choice, 1/2/4 = force a simple tile
 template <typename T, int EPI>
-static int launch_epi(const GemmArgs& a, hipStream_t s) {
+static int launch_epi(const GemmArgs& a, hipStream_t s, int variant) {
     // Large problems that do not go to the persistent ping-pong kernel (gemm_pp.hip): 256 x 256 tile on 8 waves;
     // small problems (text tower, tiny shapes): 128 x 128 on 4 waves.
     if ((size_t)a.M * a.N >= (size_t)256 * 128 * 512) {
-        switch (g_gemm_variant & 0xff) {
+        switch (variant & 0xff) {
             case 2: return launch_cfg<T, 128, 256, 2, 4, EPI>(a, s);
             case 4: return launch_cfg<T, 256, 128, 4, 2, EPI>(a, s);
             default: return launch_cfg<T, 256, 256, 2, 4, EPI>(a, s);
@@ -206,34 +206,35 @@ static int launch_epi(const GemmArgs& a, hipStream_t s) {
     // fewer 128 x 128 tiles than half the CUs: every workgroup is a latency chain over K -- narrower tiles (twice the
     // workgroups) and a 4-deep ring.  gemm_variant 5 / 6 force the shallow / deep form (A/B runs).
     const size_t t128 = (size_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const int v = g_gemm_variant & 0xff;
+    const int v = variant & 0xff;
     if ((t128 <= 128 && v != 5) || v == 6) return launch_cfg<T, 128, 64, 2, 2, EPI, 4>(a, s);
     return launch_cfg<T, 128, 128, 2, 2, EPI>(a, s);
 }
 
 template <typename T>
-static int launch_t(int epi, const GemmArgs& a, hipStream_t s) {
+static int launch_t(int epi, const GemmArgs& a, hipStream_t s, int variant) {
     switch (epi) {
-        case EPI_STORE: return launch_epi<T, EPI_STORE>(a, s);
-        case EPI_GELU: return launch_epi<T, EPI_GELU>(a, s);
-        case EPI_RESIDUAL: return launch_epi<T, EPI_RESIDUAL>(a, s);
-        case EPI_GELU_BWD: return launch_epi<T, EPI_GELU_BWD>(a, s);
-        case EPI_PATCH: return launch_epi<T, EPI_PATCH>(a, s);
-        case EPI_STORE_F32: return launch_epi<T, EPI_STORE_F32>(a, s);
+        case EPI_STORE: return launch_epi<T, EPI_STORE>(a, s, variant);
+        case EPI_GELU: return launch_epi<T, EPI_GELU>(a, s, variant);
+        case EPI_RESIDUAL: return launch_epi<T, EPI_RESIDUAL>(a, s, variant);
+        case EPI_GELU_BWD: return launch_epi<T, EPI_GELU_BWD>(a, s, variant);
+        case EPI_PATCH: return launch_epi<T, EPI_PATCH>(a, s, variant);
+        case EPI_STORE_F32: return launch_epi<T, EPI_STORE_F32>(a, s, variant);
     }
     set_error("gemm: unknown epilogue %d", epi);
     return MUDPT_ERR_ARG;
 }
 
 // default dispatch: the persistent ping-pong kernel takes the big GEMMs whose epilogue needs no operand load besides bias / u
-bool gemm_uses_pp(int epi, const GemmArgs& a) {
+bool gemm_uses_pp(int epi, const GemmArgs& a, int variant) {
     const bool pp_epi = epi == EPI_STORE || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32;
-    const int v = g_gemm_variant & 0xff;
+    const int v = variant & 0xff;
     return (v == 0 || v == 3 || v == 5 || v == 6) && pp_epi && !a.out1_lo && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
            (epi != EPI_GELU_BWD || a.ldaux % 8 == 0);
 }
 
-int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
+int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
+    const int variant = o.variant;
     ARG_CHECK(a.A && a.B && a.out0, "gemm: null operand");
     ARG_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
     ARG_CHECK(a.K % 64 == 0, "gemm: K=%d must be a multiple of 64", a.K);
@@ -245,13 +246,13 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_RESIDUAL || epi == EPI_GELU_BWD) ARG_CHECK(a.aux && a.ldaux >= a.N && a.ldaux % 4 == 0, "gemm: epilogue needs aux");
     if (epi == EPI_PATCH) ARG_CHECK(a.pos && a.patches > 0 && a.seq_len > a.patches && a.M % a.patches == 0, "gemm: bad patch epilogue args");
     GemmArgs b = a;
-    if (g_gemm_variant & 0x100) b.flags |= 1;
-    if (g_gemm_variant & 0x200) b.flags |= 2;  // gemm_pp: no half tiles in the last wave
-    b.flags |= ((g_gemm_variant >> 12) & 0xff) << 8;  // bits 12..19 of the knob: column-tile group width GN of gemm_pp (0 = default)
+    if (variant & 0x100) b.flags |= 1;
+    if (variant & 0x200) b.flags |= 2;  // gemm_pp: no half tiles in the last wave
+    b.flags |= ((variant >> 12) & 0xff) << 8;  // bits 12..19 of the knob: column-tile group width GN of gemm_pp (0 = default)
     // default: the persistent ping-pong kernel for the big GEMMs whose epilogue needs no operand load besides bias / u
-    if (gemm_uses_pp(epi, a)) return launch_gemm_pp(dtype, epi, b, s);
-    if (dtype == DT_BF16) return launch_t<BF16>(epi, b, s);
-    if (dtype == DT_F16) return launch_t<F16>(epi, b, s);
+    if (gemm_uses_pp(epi, a, o.variant)) return launch_gemm_pp(dtype, epi, b, s, o);
+    if (dtype == DT_BF16) return launch_t<BF16>(epi, b, s, o.variant);
+    if (dtype == DT_F16) return launch_t<F16>(epi, b, s, o.variant);
     set_error("gemm: unknown dtype %d", dtype);
     return MUDPT_ERR_ARG;
 }

@@ -23,8 +23,6 @@
 
 namespace mudpt {
 
-hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;  // set by the caller for ONE launch (bench.py's roofline leg)
-
 using lptr_t = __attribute__((address_space(3))) void*;
 
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -377,29 +375,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
 }
 
 template <typename T, int EPI>
-static int launch_pp(const GemmArgs& a, hipStream_t s) {
+static int launch_pp(const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
     constexpr int lds = 2 * 65536;
     auto kern = gemm_pp_kernel<T, EPI>;
-    static bool attr_set = false;
-    static int ncu = 0;
-    if (!attr_set) {
+    static PerDevice pd;
+    const int dev = current_device();
+    if (!pd.done[dev]) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_set = true;
+        HIP_TRY(hipDeviceGetAttribute(&pd.ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+        pd.done[dev] = true;
     }
+    const int ncu = pd.ncu[dev];
     const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256, ntiles = ntm * ntn;
     // grid = CUs; a last partial wave of R tiles with 2 R <= grid is run as 2 R half tiles (see the kernel); fewer tiles
     // than half the CUs: every tile is split
     int grid = ntiles < ncu ? (2 * ntiles <= ncu ? 2 * ntiles : ntiles) : ncu;
     if (a.flags & 2) grid = ntiles < ncu ? ntiles : ncu;  // tuning knob: no half tiles
     const int rem = ntiles % grid, rem_half = (rem > 0 && 2 * rem <= grid && !(a.flags & 2)) ? rem : 0;
-    if (g_prof_start && g_prof_stop) {
+    if (o.ev_start && o.ev_stop) {
         // measurement mode: the two events ride on the kernel's own dispatch packet (no marker packets between kernels, which
         // cost ~7 us per pair and serialise the queue)
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g_prof_start, g_prof_stop, 0, a, ntn, ntiles, rem_half);
-        g_prof_start = g_prof_stop = nullptr;
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, o.ev_start, o.ev_stop, 0, a, ntn, ntiles, rem_half);
     } else {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, ntn, ntiles, rem_half);
     }
@@ -408,25 +404,25 @@ static int launch_pp(const GemmArgs& a, hipStream_t s) {
 }
 
 template <typename T>
-static int launch_pp_t(int epi, const GemmArgs& a, hipStream_t s) {
+static int launch_pp_t(int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
     switch (epi) {
-        case EPI_STORE: return launch_pp<T, EPI_STORE>(a, s);
-        case EPI_GELU: return launch_pp<T, EPI_GELU>(a, s);
-        case EPI_GELU_BWD: return launch_pp<T, EPI_GELU_BWD>(a, s);
-        case EPI_STORE_F32: return launch_pp<T, EPI_STORE_F32>(a, s);
+        case EPI_STORE: return launch_pp<T, EPI_STORE>(a, s, o);
+        case EPI_GELU: return launch_pp<T, EPI_GELU>(a, s, o);
+        case EPI_GELU_BWD: return launch_pp<T, EPI_GELU_BWD>(a, s, o);
+        case EPI_STORE_F32: return launch_pp<T, EPI_STORE_F32>(a, s, o);
     }
     set_error("gemm_pp: epilogue %d is not built for the ping-pong kernel", epi);
     return MUDPT_ERR_ARG;
 }
 
 // Arguments are validated by launch_gemm (gemm.hip) before it dispatches here.
-int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
+int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
     ARG_CHECK((size_t)a.M * a.lda * 2 < 0xffffffffull && (size_t)a.N * a.ldb * 2 < 0xffffffffull, "gemm_pp: operand larger than 4 GiB");
     ARG_CHECK(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldo0 % 8 == 0, "gemm_pp: strides must be multiples of 8");
     // epilogue offsets are 32-bit and rely on the descriptors' range check for rows >= M
     ARG_CHECK((size_t)a.M * a.ldo0 * 4 < 0x7fffffffull && (size_t)a.M * (size_t)(a.ldo1 > a.ldaux ? a.ldo1 : a.ldaux) * 2 < 0x7fffffffull, "gemm_pp: output larger than 2 GiB");
-    if (dtype == DT_BF16) return launch_pp_t<BF16>(epi, a, s);
-    if (dtype == DT_F16) return launch_pp_t<F16>(epi, a, s);
+    if (dtype == DT_BF16) return launch_pp_t<BF16>(epi, a, s, o);
+    if (dtype == DT_F16) return launch_pp_t<F16>(epi, a, s, o);
     set_error("gemm: unknown dtype %d", dtype);
     return MUDPT_ERR_ARG;
 }

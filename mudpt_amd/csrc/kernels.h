@@ -32,11 +32,14 @@ struct GemmArgs {
     int patches = 0, seq_len = 0;  // EPI_PATCH: P, L
     const float* pos = nullptr;    // EPI_PATCH: [1 + P, N]
 };
-int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s);
-extern int g_gemm_variant;  // tuning knob, see gemm.hip
-bool gemm_uses_pp(int epi, const GemmArgs& a);  // true if launch_gemm dispatches to gemm_pp_kernel
-extern hipEvent_t g_prof_start, g_prof_stop;     // if set, the next gemm_pp_kernel launch records them (start / end of the kernel)
-int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s);  // persistent 256x256 ping-pong kernel (gemm_pp.hip)
+// Host-side options of one launch (never passed to the device): they belong to the calling model handle, not to the process.
+struct GemmOpts {
+    int variant = 0;                                 // tuning knob, see gemm.hip (mudpt_model_set "gemm_variant")
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // if set, a gemm_pp_kernel launch records them (start / end of the kernel)
+};
+int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o = GemmOpts());
+bool gemm_uses_pp(int epi, const GemmArgs& a, int variant = 0);  // true if launch_gemm dispatches to gemm_pp_kernel
+int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o);  // persistent 256x256 ping-pong kernel (gemm_pp.hip)
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (fp32 statistics, eps 1e-5; clip/model.py:164-170).

@@ -11,6 +11,7 @@
 //   MLP pre-activation: 0.95 GB per block at B = 256, 11.4 GB for the vision tower (288 GB HBM: no recompute).
 // Prompt rows are ordinary rows of the token buffer: the reference's torch.cat splices
 // (clip/model.py:281-297) are in-place row writes, their backward a fixed-order reduction over the batch.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -145,8 +146,12 @@ struct mudpt_model {
     float *mn_hid = nullptr, *mn_bias = nullptr, *mn_dbias = nullptr, *mn_dhid = nullptr;  // [B, hid], [B, dt], [B, dt], [B, hid]
     float loss_scale = 128.f;  // static, power of two; see mudpt_forward_backward
     // bf16 mode keeps the gradient of the residual stream in T only (the fp32 copy costs 237 MB of HBM traffic per
-    // LayerNorm backward); fp16 mode -- the parity configuration -- keeps it in fp32.  mudpt_debug_set("lp_grad") overrides.
+    // LayerNorm backward); fp16 mode -- the parity configuration -- keeps it in fp32.  mudpt_model_set("lp_grad") overrides.
     bool lp_grad = false;
+    // per-handle tuning knobs (mudpt_model_set): nothing here is process-global, two models in one process do not interfere
+    int gemm_variant = 0;
+    bool txt_trim = true;  // run the text tower on positions 0..max(eot) only (read by mudpt_set_class_prompts)
+    bool any_weight_set = false;
     // side stream for the text tower (forks after the prompt learner / head backward, joins before the head /
     // prompt-learner backward)
     hipStream_t s2 = nullptr;
@@ -163,7 +168,9 @@ struct mudpt_model {
 static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s) {
     // only the dominant kernel is bracketed: gemm_pp_kernel launches (the vision tower's big GEMMs, main stream).  The text
     // tower's small GEMMs run on the side stream, where an event pair would mostly measure queueing behind the other stream.
-    if (!m->prof || !gemm_uses_pp(epi, a)) return launch_gemm(m->dtype, epi, a, s);
+    GemmOpts o;
+    o.variant = m->gemm_variant;
+    if (!m->prof || !gemm_uses_pp(epi, a, o.variant)) return launch_gemm(m->dtype, epi, a, s, o);
     if (m->ev_used + 2 > m->ev.size()) {
         for (int i = 0; i < 512; ++i) {
             hipEvent_t e;
@@ -171,18 +178,13 @@ static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s) 
             m->ev.push_back(e);
         }
     }
-    g_prof_start = m->ev[m->ev_used];
-    g_prof_stop = m->ev[m->ev_used + 1];
-    const int rc = launch_gemm(m->dtype, epi, a, s);
-    g_prof_start = g_prof_stop = nullptr;
+    o.ev_start = m->ev[m->ev_used];
+    o.ev_stop = m->ev[m->ev_used + 1];
+    const int rc = launch_gemm(m->dtype, epi, a, s, o);
     m->ev_used += 2;
     m->ev_flop.push_back(2.0 * a.M * a.N * a.K);
     return rc;
 }
-
-static bool g_lp_grad_default = true;
-static bool g_txt_trim_default = true;   // run the text tower on positions 0..max(eot) only; mudpt_debug_set("txt_trim")
-static bool g_txt_split_default = true;  // fp16 mode: split operands in the text tower (Tower::split); mudpt_debug_set("txt_split")
 
 static const char* kParamNames[10] = {
     "mudpt_prompt_learner.ctx",
@@ -291,14 +293,14 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     mudpt_model* m = new mudpt_model();
     m->cfg = *c;
     m->dtype = c->dtype;
-    m->lp_grad = (c->dtype == MUDPT_BF16) && g_lp_grad_default;
+    m->lp_grad = (c->dtype == MUDPT_BF16);
     m->cocoop = cocoop;
     if (cocoop) m->cfg.depth = 1;  // no deep prompts
     const int dv = c->v_width, dt = c->t_width, e = c->embed_dim, n = c->n_ctx, D1 = m->cfg.depth - 1, B = c->max_batch, C = c->n_cls;
     const int TS = cocoop ? B * C : C;  // text sequences per step: one per (image, class) pair in CoCoOp (trainers/cocoop.py:187-194)
     auto fail = [&](int code) { mudpt_destroy(m); return code; };
     if (int r = alloc_tower(m, m->vis, dv, c->v_layers, c->v_heads, Lv, B, false, cocoop ? Lv : Lv - n)) return fail(r);
-    if (int r = alloc_tower(m, m->txt, dt, c->t_layers, c->t_heads, c->ctx_len, TS, true, 1, c->dtype == MUDPT_F16 && g_txt_split_default)) return fail(r);
+    if (int r = alloc_tower(m, m->txt, dt, c->t_layers, c->t_heads, c->ctx_len, TS, true, 1, c->dtype == MUDPT_F16)) return fail(r);
     auto body = [&]() -> int {
         const int K0 = (3 * c->patch * c->patch + 63) / 64 * 64;  // conv-as-GEMM K, zero-padded to the GEMM's granularity (ViT-L/14: 588 -> 640)
         ALLOC(m->conv_w, (size_t)dv * K0 * 2);
@@ -472,6 +474,7 @@ extern "C" int mudpt_set_weight(mudpt_model* m, const char* key, const float* da
     else { set_error("set_weight: unknown key '%s'", key); return MUDPT_ERR_ARG; }
 #undef EXPECT
     if (rc) return rc;
+    m->any_weight_set = true;
     for (size_t i = 0; i < m->missing.size(); ++i)
         if (m->missing[i] == k) { m->missing.erase(m->missing.begin() + i); break; }
     return MUDPT_OK;
@@ -487,13 +490,13 @@ extern "C" int mudpt_set_class_prompts(mudpt_model* m, const float* emb, const i
     // (trainers/mudpt.py:154): positions behind the last EOT of the class set influence neither a used output nor a gradient,
     // so the tower runs on the first Le = max(eot) + 1 positions of every prompt ("a photo of a <name>." ends at position 7-9
     // of 77).  Row-wise operators and causal attention make the kept rows bit-identical to the full-length run;
-    // mudpt_debug_set("txt_trim", 0) keeps all ctx_len positions (A/B runs, tests).
+    // mudpt_model_set("txt_trim", 0) keeps all ctx_len positions (A/B runs, tests).
     int max_eot = 0;
     for (size_t cc = 0; cc < C; ++cc) {
         ARG_CHECK(eot[cc] >= 0 && eot[cc] < (int)L, "set_class_prompts: eot index %d out of range", eot[cc]);
         max_eot = std::max(max_eot, (int)eot[cc]);
     }
-    const size_t Le = g_txt_trim_default ? (size_t)std::max(max_eot + 1, c.n_ctx + 2) : L;
+    const size_t Le = m->txt_trim ? (size_t)std::max(max_eot + 1, c.n_ctx + 2) : L;
     m->txt.L = (int)Le;
     m->txt.Lp = attn_padded_len((int)Le);
     std::vector<float> pos(L * d), ep(C * Le * d);
@@ -966,20 +969,54 @@ extern "C" int mudpt_sgd_reset(mudpt_model* m) {
     return MUDPT_OK;
 }
 
+// ---- data-parallel exchange for hosts without torch.distributed ---------------------------------------------------------------
+// The ONE collective of a step: sum of the flat gradient bucket over the ranks of an RCCL communicator the caller
+// created (ncclCommInitRank; one process per GPU).  RCCL is resolved at first use from the process (librccl.so.1, the SONAME torch
+// ships and /opt/rocm installs), so the library has no link-time dependency on it and single-GPU hosts never load it.
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static nccl_allreduce_fn resolve_allreduce() {
+    static nccl_allreduce_fn fn = nullptr;
+    if (fn) return fn;
+    void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    if (!sym) {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {  // returns the already-loaded copy when the process has one
+                sym = dlsym(h, "ncclAllReduce");
+                if (sym) break;
+            }
+        }
+    }
+    fn = (nccl_allreduce_fn)sym;
+    return fn;
+}
+extern "C" int mudpt_allreduce_grads(mudpt_model* m, void* nccl_comm, void* stream) {
+    ARG_CHECK(m && nccl_comm, "allreduce_grads: null model / communicator");
+    if (!m->grads) { set_error("allreduce_grads: no gradient bucket bound"); return MUDPT_ERR_STATE; }
+    nccl_allreduce_fn fn = resolve_allreduce();
+    if (!fn) { set_error("allreduce_grads: RCCL (librccl.so.1) is not loadable in this process: %s", dlerror()); return MUDPT_ERR_STATE; }
+    const int rc = fn(m->grads, m->grads, m->total, /*ncclFloat32*/ 7, /*ncclSum*/ 0, nccl_comm, (hipStream_t)stream);
+    if (rc != 0) { set_error("allreduce_grads: ncclAllReduce failed with ncclResult_t %d", rc); return MUDPT_ERR_HIP; }
+    return MUDPT_OK;
+}
+
 extern "C" int mudpt_set_loss_scale(mudpt_model* m, float loss_scale) {
     ARG_CHECK(m && loss_scale > 0.f && std::isfinite(loss_scale), "set_loss_scale: scale must be positive and finite");
     m->loss_scale = loss_scale;
     return MUDPT_OK;
 }
 
-// Tuning knobs for A/B runs in one process (tools/gemm_bench.py); not part of the product surface.
-extern "C" int mudpt_debug_set(const char* name, int32_t value) {
-    ARG_CHECK(name, "debug_set: null name");
-    if (!strcmp(name, "gemm_variant")) { g_gemm_variant = value; return MUDPT_OK; }
-    if (!strcmp(name, "lp_grad")) { g_lp_grad_default = value != 0; return MUDPT_OK; }
-    if (!strcmp(name, "txt_trim")) { g_txt_trim_default = value != 0; return MUDPT_OK; }  // applies to the next mudpt_set_class_prompts
-    if (!strcmp(name, "txt_split")) { g_txt_split_default = value != 0; return MUDPT_OK; }  // applies to models created afterwards
-    set_error("debug_set: unknown knob '%s'", name);
+// Per-handle tuning knobs for A/B runs in one process (tools/gemm_bench.py, tests); state of THIS model only.
+extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) {
+    ARG_CHECK(m && name, "model_set: null argument");
+    if (!strcmp(name, "gemm_variant")) { m->gemm_variant = value; return MUDPT_OK; }
+    if (!strcmp(name, "lp_grad")) { m->lp_grad = value != 0 && m->dtype == MUDPT_BF16; return MUDPT_OK; }  // both stream copies are always allocated
+    if (!strcmp(name, "txt_trim")) { m->txt_trim = value != 0; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
+    if (!strcmp(name, "txt_split")) {  // the [W | W] copies are made while the weights are ingested: decide before the first mudpt_set_weight
+        if (m->any_weight_set) { set_error("model_set: txt_split must be set before the first mudpt_set_weight"); return MUDPT_ERR_STATE; }
+        m->txt.split = value != 0 && m->dtype == MUDPT_F16;
+        return MUDPT_OK;
+    }
+    set_error("model_set: unknown knob '%s'", name);
     return MUDPT_ERR_ARG;
 }
 
@@ -1040,10 +1077,12 @@ extern "C" int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch,
 // ---- single kernels ---------------------------------------------------------------------------------------------
 extern "C" int mudpt_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
                           const float* bias, void* out0, int32_t ldo0, void* out1, int32_t ldo1, const void* aux, int32_t ldaux, int32_t patches,
-                          int32_t seq_len, const float* pos, void* stream) {
+                          int32_t seq_len, const float* pos, int32_t variant, void* stream) {
+    GemmOpts o;
+    o.variant = variant;
     GemmArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias; a.out0 = out0; a.ldo0 = ldo0; a.out1 = out1; a.ldo1 = ldo1;
     a.aux = aux; a.ldaux = ldaux; a.patches = patches; a.seq_len = seq_len; a.pos = pos;
-    return launch_gemm(dtype, epi, a, (hipStream_t)stream);
+    return launch_gemm(dtype, epi, a, (hipStream_t)stream, o);
 }
 extern "C" int mudpt_layernorm_fwd(int32_t dtype, const float* x, int32_t ldx, const int32_t* row_index, const float* gamma, const float* beta, void* out,
                                    int32_t ldo, int32_t out_f32, float* mean, float* rstd, int32_t rows, int32_t d, void* stream) {

@@ -57,7 +57,7 @@ class _Holder(nn.Module):
 class CustomCLIP(nn.Module):
     def __init__(self, shape: ModelShape, clip_state: Dict[str, torch.Tensor], tokenized_prompts: torch.Tensor,
                  ctx_token_ids: Optional[Sequence[int]] = None, max_batch: int = 256, dtype: str = "bf16",
-                 device: str = "cuda:0", seed: Optional[int] = None, variant: str = "mudpt"):
+                 device: str = "cuda:0", seed: Optional[int] = None, variant: str = "mudpt", knobs: Optional[Dict[str, int]] = None):
         super().__init__()
         if not torch.cuda.is_available():
             raise capi.MudptError("mudpt_amd needs an MI355X (HIP device); there is no CPU path in the product")
@@ -79,6 +79,8 @@ class CustomCLIP(nn.Module):
         h = C.c_void_p()
         capi.check(self.lib.mudpt_create(C.byref(cfg), C.byref(h)), "create")
         self._h = h
+        for name, value in (knobs or {}).items():  # per-handle tuning knobs (mudpt_model_set): A/B runs and tests
+            self.set_knob(name, value)
         # frozen weights, by OpenAI CLIP key (clip/model.py:919 load_state_dict)
         for k, v in clip_state.items():
             if k == "token_embedding.weight" or not isinstance(v, torch.Tensor):
@@ -134,6 +136,11 @@ class CustomCLIP(nn.Module):
     @property
     def ctx_key(self) -> str:
         return "mudpt_prompt_learner.ctx" if self.variant == "mudpt" else "prompt_learner.ctx"
+
+    def set_knob(self, name: str, value: int):
+        """``mudpt_model_set``: "gemm_variant", "lp_grad" any time; "txt_split" / "txt_trim" only through ``knobs=`` at construction
+        (before the weights / class prompts are ingested)."""
+        capi.check(self.lib.mudpt_model_set(self._h, name.encode(), int(value)), f"model_set({name})")
 
     def set_params(self, tensors: Dict[str, torch.Tensor]):
         self._text_version = None

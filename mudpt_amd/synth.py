@@ -44,41 +44,54 @@ def synthetic_tokenized_prompts(n_cls: int, n_ctx: int = 4, ctx_len: int = 77, s
     return tok
 
 
+def clip_state_table(shape: ModelShape):
+    """(key, tensor shape, init) of every entry of a CLIP ViT state dict (clip/model.py:667-808): init is a std for N(0, std^2)
+    entries, "ones" / "zeros" for LayerNorm affine terms and attention biases."""
+    dv, dt, e = shape.v_width, shape.t_width, shape.embed_dim
+    P = (shape.image_size // shape.patch) ** 2
+    rows = [
+        ("visual.conv1.weight", (dv, 3, shape.patch, shape.patch), (3 * shape.patch ** 2) ** -0.5),
+        ("visual.class_embedding", (dv,), dv ** -0.5),
+        ("visual.positional_embedding", (P + 1, dv), dv ** -0.5),
+        ("visual.ln_pre.weight", (dv,), "ones"), ("visual.ln_pre.bias", (dv,), "zeros"),
+        ("visual.ln_post.weight", (dv,), "ones"), ("visual.ln_post.bias", (dv,), "zeros"),
+        ("visual.proj", (dv, e), dv ** -0.5),
+        ("token_embedding.weight", (VOCAB, dt), 0.02),
+        ("positional_embedding", (shape.ctx_len, dt), 0.01),
+        ("ln_final.weight", (dt,), "ones"), ("ln_final.bias", (dt,), "zeros"),
+        ("text_projection", (dt, e), dt ** -0.5),
+    ]
+    for prefix, d, layers in (("visual.transformer", dv, shape.v_layers), ("transformer", dt, shape.t_layers)):
+        for i in range(layers):
+            p = f"{prefix}.resblocks.{i}."
+            rows += [(p + "ln_1.weight", (d,), "ones"), (p + "ln_1.bias", (d,), "zeros"),
+                     (p + "ln_2.weight", (d,), "ones"), (p + "ln_2.bias", (d,), "zeros"),
+                     (p + "attn.in_proj_weight", (3 * d, d), d ** -0.5), (p + "attn.in_proj_bias", (3 * d,), "zeros"),
+                     (p + "attn.out_proj.weight", (d, d), d ** -0.5 * (2 * layers) ** -0.5), (p + "attn.out_proj.bias", (d,), "zeros"),
+                     (p + "mlp.c_fc.weight", (4 * d, d), (2 * d) ** -0.5), (p + "mlp.c_fc.bias", (4 * d,), 0.02),
+                     (p + "mlp.c_proj.weight", (d, 4 * d), d ** -0.5 * (2 * layers) ** -0.5), (p + "mlp.c_proj.bias", (d,), 0.02)]
+    return rows
+
+
+def random_clip_state_shapes(shape: ModelShape) -> Dict[str, torch.Tensor]:
+    """Uninitialised tensors of a CLIP state dict's shapes (under ``torch.device("meta")``: shapes only), for shape inference."""
+    sd = {k: torch.empty(s) for k, s, _ in clip_state_table(shape)}
+    sd["logit_scale"] = torch.empty(())
+    return sd
+
+
 def random_clip_state(shape: ModelShape, seed: int = 0, fp16_weights: bool = True) -> Dict[str, torch.Tensor]:
     """Random CLIP weights with the distributions of CLIP.initialize_parameters (clip/model.py:781-808) and the
     vision tower's width^-1/2 scale (clip/model.py:506-508,524); random, not zeros (zeros inflate clocks)."""
     g = torch.Generator().manual_seed(seed)
-    dv, dt, e = shape.v_width, shape.t_width, shape.embed_dim
-    P = (shape.image_size // shape.patch) ** 2
-
-    def rn(*s, std=1.0):
-        t = torch.randn(*s, generator=g) * std
-        return t.half().float() if fp16_weights else t
-
-    sd = {
-        "visual.conv1.weight": rn(dv, 3, shape.patch, shape.patch, std=(3 * shape.patch ** 2) ** -0.5),
-        "visual.class_embedding": rn(dv, std=dv ** -0.5),
-        "visual.positional_embedding": rn(P + 1, dv, std=dv ** -0.5),
-        "visual.ln_pre.weight": torch.ones(dv), "visual.ln_pre.bias": torch.zeros(dv),
-        "visual.ln_post.weight": torch.ones(dv), "visual.ln_post.bias": torch.zeros(dv),
-        "visual.proj": rn(dv, e, std=dv ** -0.5),
-        "token_embedding.weight": rn(VOCAB, dt, std=0.02),
-        "positional_embedding": rn(shape.ctx_len, dt, std=0.01),
-        "ln_final.weight": torch.ones(dt), "ln_final.bias": torch.zeros(dt),
-        "text_projection": rn(dt, e, std=dt ** -0.5),
-        "logit_scale": torch.tensor(math.log(1 / 0.07)),
-    }
-    for prefix, d, layers in (("visual.transformer", dv, shape.v_layers), ("transformer", dt, shape.t_layers)):
-        for i in range(layers):
-            p = f"{prefix}.resblocks.{i}."
-            sd[p + "ln_1.weight"], sd[p + "ln_1.bias"] = torch.ones(d), torch.zeros(d)
-            sd[p + "ln_2.weight"], sd[p + "ln_2.bias"] = torch.ones(d), torch.zeros(d)
-            sd[p + "attn.in_proj_weight"] = rn(3 * d, d, std=d ** -0.5)
-            sd[p + "attn.in_proj_bias"] = torch.zeros(3 * d)
-            sd[p + "attn.out_proj.weight"] = rn(d, d, std=d ** -0.5 * (2 * layers) ** -0.5)
-            sd[p + "attn.out_proj.bias"] = torch.zeros(d)
-            sd[p + "mlp.c_fc.weight"] = rn(4 * d, d, std=(2 * d) ** -0.5)
-            sd[p + "mlp.c_fc.bias"] = rn(4 * d, std=0.02)
-            sd[p + "mlp.c_proj.weight"] = rn(d, 4 * d, std=d ** -0.5 * (2 * layers) ** -0.5)
-            sd[p + "mlp.c_proj.bias"] = rn(d, std=0.02)
+    sd = {}
+    for k, s, init in clip_state_table(shape):
+        if init == "ones":
+            sd[k] = torch.ones(s)
+        elif init == "zeros":
+            sd[k] = torch.zeros(s)
+        else:
+            t = torch.randn(*s, generator=g) * init
+            sd[k] = t.half().float() if fp16_weights else t
+    sd["logit_scale"] = torch.tensor(math.log(1 / 0.07))
     return sd

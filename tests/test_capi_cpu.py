@@ -44,6 +44,10 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
         capi.check(1, "create")
 
 
+def test_allreduce_entry_point_validates_before_touching_rccl(lib):
+    assert lib.mudpt_allreduce_grads(None, None, None) == 1 and b"null model" in lib.mudpt_last_error()
+
+
 def test_product_does_not_import_the_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for dirpath, _, files in os.walk(os.path.join(root, "mudpt_amd")):

@@ -27,12 +27,12 @@ def ok(lib, rc):
     assert rc == 0, lib.mudpt_last_error().decode()
 
 
-def gemm(lib, dt, epi, A, B, bias=None, out0=None, out1=None, aux=None, patches=0, seq_len=0, pos=None):
+def gemm(lib, dt, epi, A, B, bias=None, out0=None, out1=None, aux=None, patches=0, seq_len=0, pos=None, variant=0):
     M, K = A.shape
     N = B.shape[0]
     ok(lib, lib.mudpt_gemm(dt, epi, M, N, K, P(A), A.stride(0), P(B), B.stride(0), P(bias), P(out0), out0.stride(0),
                            P(out1), out1.stride(0) if out1 is not None else 0, P(aux), aux.stride(0) if aux is not None else 0,
-                           patches, seq_len, P(pos), None))
+                           patches, seq_len, P(pos), variant, None))
     torch.cuda.synchronize()
 
 
@@ -131,7 +131,7 @@ def test_gemm_patch_epilogue(lib, dtype):
 def test_gemm_rejects_bad_shapes(lib):
     A = torch.zeros(64, 96, device="cuda", dtype=torch.bfloat16)
     out = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
-    rc = lib.mudpt_gemm(0, 0, 64, 64, 96, P(A), 96, P(A), 96, None, P(out), 64, None, 0, None, 0, 0, 0, None, None)
+    rc = lib.mudpt_gemm(0, 0, 64, 64, 96, P(A), 96, P(A), 96, None, P(out), 64, None, 0, None, 0, 0, 0, None, 0, None)
     assert rc == 1 and b"multiple of 64" in lib.mudpt_last_error()
 
 
@@ -383,17 +383,9 @@ def test_attention_softmax_extremes(lib):
     torch.testing.assert_close(out.cpu().float(), ref, atol=4e-3, rtol=4e-3)
 
 
-@pytest.fixture
-def gemm_variant(lib):
-    def set_variant(v):
-        assert lib.mudpt_debug_set(b"gemm_variant", v) == 0
-    yield set_variant
-    lib.mudpt_debug_set(b"gemm_variant", 0)
-
-
 @pytest.mark.parametrize("variant", [0, 1, 2, 4])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_gemm_variants_exact_integers(lib, gemm_variant, variant, dtype):
+def test_gemm_variants_exact_integers(lib, variant, dtype):
     """Every large-problem GEMM kernel (0 = default: persistent ping-pong kernel; 1, 2, 4 = simple 256x256, 128x256,
     256x128 tiles): exact small-integer operands, ragged M, asymmetric B, K spanning several tiles -> bit-exact."""
     dt, tt = DT[dtype]
@@ -403,14 +395,13 @@ def test_gemm_variants_exact_integers(lib, gemm_variant, variant, dtype):
     B = (torch.arange(N).view(N, 1) % 7 - 3 + (torch.arange(K).view(1, K) % 3)).float()
     ref = A @ B.t()
     out = torch.full((M, N), -1.0, device="cuda", dtype=torch.float32)
-    gemm_variant(variant)
-    gemm(lib, dt, 5, A.cuda().to(tt), B.cuda().to(tt), out0=out)
+    gemm(lib, dt, 5, A.cuda().to(tt), B.cuda().to(tt), out0=out, variant=variant)
     assert torch.equal(out.cpu(), ref)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(33000, 768, 768), (8200, 2304, 768), (22000, 768, 3072)])
-def test_gemm_pingpong_epilogues(lib, gemm_variant, dtype, shape):
+def test_gemm_pingpong_epilogues(lib, dtype, shape):
     dt, tt = DT[dtype]
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N + K)
@@ -421,7 +412,7 @@ def test_gemm_pingpong_epilogues(lib, gemm_variant, dtype, shape):
     Ad, Bd, bd = A.cuda(), B.cuda(), bias.cuda()
     tol = dict(atol=4 * EPS[dtype], rtol=4 * EPS[dtype])
     f32tol = dict(atol=3e-5 * K ** 0.5, rtol=2e-5)
-    gemm_variant(0)  # default dispatch: ping-pong kernel for store / GELU / GELU' / fp32 store, simple 256x256 for residual
+    # default dispatch (variant 0): ping-pong kernel for store / GELU / GELU' / fp32 store, simple 256x256 for residual
     out = torch.empty(M, N, device="cuda", dtype=tt)
     gemm(lib, dt, 0, Ad, Bd, bias=bd, out0=out)
     torch.testing.assert_close(out.cpu().float(), acc + bias, **tol)

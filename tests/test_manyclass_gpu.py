@@ -26,11 +26,11 @@ LOGIT_ATOL = {"fp16": 1e-3, "bf16": 3.2e-2}
 GRAD_RTOL = {"fp16": 2e-2, "bf16": 1.5e-1}   # relative to each gradient tensor's RMS (max error <= 4x that, cosine below)
 
 
-def build(cfg, frozen, tokens, params, dtype, max_batch):
+def build(cfg, frozen, tokens, params, dtype, max_batch, knobs=None):
     from mudpt_amd.model import CustomCLIP, ModelShape
     shape = ModelShape(cfg.image_size, cfg.patch, cfg.v_width, cfg.v_layers, cfg.v_heads, cfg.t_width, cfg.t_layers, cfg.t_heads,
                        cfg.ctx_len, cfg.embed_dim, cfg.n_ctx, cfg.depth)
-    m = CustomCLIP(shape, frozen, tokens, max_batch=max_batch, dtype=dtype)
+    m = CustomCLIP(shape, frozen, tokens, max_batch=max_batch, dtype=dtype, knobs=knobs)
     m.set_params(params)
     return m
 
@@ -85,14 +85,9 @@ def test_c208_logits_loss_grads_match_reference(case208, dtype):
 def test_c208_text_tower_trim_changes_nothing(case208):
     """Le = 26 of 77 positions with a different EOT row per class: logits, loss and gradients equal the untrimmed run up to the
     summation order inside attention (fp16 mode: split operands through the large-M GEMMs in both runs)."""
-    from mudpt_amd import capi
-    case, lib, out = case208, capi.load(), {}
+    case, out = case208, {}
     for trim in (1, 0):
-        capi.check(lib.mudpt_debug_set(b"txt_trim", trim))
-        try:
-            m = build(case.cfg, case.frozen, case.tokens, case.params, "fp16", 2)
-        finally:
-            capi.check(lib.mudpt_debug_set(b"txt_trim", 1))
+        m = build(case.cfg, case.frozen, case.tokens, case.params, "fp16", 2, knobs={"txt_trim": trim})
         loss, logits = m.forward_backward(case.images, case.labels, return_logits=True)
         out[trim] = (logits.cpu(), loss.item(), {k: g.detach().cpu().clone() for k, g in m.grads().items()})
         m.close()

@@ -21,12 +21,12 @@ TINY_SLACK = 1.5
 GRAD_RTOL = {"fp16": 2e-2, "bf16": 1.5e-1}  # relative to each gradient tensor's RMS
 
 
-def build(case: GoldenCase, dtype: str, max_batch=None):
+def build(case: GoldenCase, dtype: str, max_batch=None, knobs=None):
     from mudpt_amd.model import CustomCLIP, ModelShape
     c = case.cfg
     shape = ModelShape(c.image_size, c.patch, c.v_width, c.v_layers, c.v_heads, c.t_width, c.t_layers, c.t_heads, c.ctx_len,
                        c.embed_dim, c.n_ctx, c.depth)
-    m = CustomCLIP(shape, case.frozen, case.tokens, max_batch=max_batch or len(case.labels), dtype=dtype)
+    m = CustomCLIP(shape, case.frozen, case.tokens, max_batch=max_batch or len(case.labels), dtype=dtype, knobs=knobs)
     m.set_params(case.params)
     return m
 
@@ -198,11 +198,7 @@ def test_text_tower_trim_changes_nothing():
     lib = capi.load()
     out = {}
     for trim in (1, 0):
-        capi.check(lib.mudpt_debug_set(b"txt_trim", trim))
-        try:
-            m = build(case, "fp16")
-        finally:
-            capi.check(lib.mudpt_debug_set(b"txt_trim", 1))
+        m = build(case, "fp16", knobs={"txt_trim": trim})
         L = m.debug_read("txt.x_in.1", len(case.labels)).numel() // (11 * case.cfg.t_width)
         assert L == (int(case.eot.max()) + 1 if trim else case.cfg.ctx_len)
         loss = m.forward_backward(case.images, case.labels)

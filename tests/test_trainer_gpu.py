@@ -67,3 +67,73 @@ def test_cocoop_trainer_steps_and_checkpoint_roundtrip(tmp_path):
     for k, v in t.model.state_dict().items():
         assert torch.equal(v, before[k]), k
     assert torch.allclose(t.model_inference(batch["img"].cuda()), logits, atol=1e-5)
+
+
+def test_backbone_from_checkpoint_files_equals_the_in_memory_path(tmp_path):
+    """MODEL.BACKBONE.PATH (trainers/mudpt.py:20-38 -> clip/clip.py:95-144): a plain state-dict file and a torch.jit archive, both
+    holding convert_weights' fp16 tensors (clip/model.py:857-878), give the same logits BIT FOR BIT as the same weights handed over
+    in memory -- shape inference (clip/model.py:885-904), fp16 -> fp32 widening and key routing are the only things in between."""
+    from mudpt_amd import dassl_lite, synth, trainer
+    from mudpt_amd.model import ModelShape
+    from tests.test_checkpoint_cpu import _Tree, as_checkpoint
+    shape = ModelShape(n_ctx=4, depth=12)
+    ck = as_checkpoint(synth.random_clip_state(shape, seed=0))
+    ck["input_resolution"] = torch.tensor(224)
+    plain, jit = tmp_path / "ViT-B-16.state.pt", tmp_path / "ViT-B-16.jit.pt"
+    torch.save(ck, plain)
+    torch.jit.save(torch.jit.script(_Tree(ck)), str(jit))
+    del ck
+    logits = {}
+    for tag, path in (("memory", ""), ("plain", str(plain)), ("jit", str(jit))):
+        cfg = dassl_lite.default_cfg()
+        cfg.OUTPUT_DIR = str(tmp_path)
+        cfg.DATASET.NUM_TRAIN, cfg.DATASET.NUM_TEST = 4, 4
+        cfg.DATALOADER.TEST.BATCH_SIZE = 4
+        cfg.MODEL.BACKBONE.PATH = path
+        cfg.TRAINER.MUDPT.N_CTX, cfg.TRAINER.MUDPT.DEEP_PROMPT_DEPTH = 4, 12
+        t = dassl_lite.build_trainer(cfg)
+        assert t.model.shape == shape
+        t.set_model_mode("eval")
+        logits[tag] = t.model_inference(t.train_loader_x[0]["img"].cuda()).clone()
+        t.model.close()
+    assert torch.isfinite(logits["memory"]).all()
+    assert torch.equal(logits["plain"], logits["memory"]) and torch.equal(logits["jit"], logits["memory"])
+
+
+def test_c_abi_allreduce_over_a_one_rank_rccl_communicator():
+    """mudpt_allreduce_grads (include/mudpt.h; the exchange a non-Python host would call): with a world-size-1 RCCL communicator the
+    sum over ranks is the identity, so the bound gradient bucket must come back bit for bit -- this exercises the lazy RCCL
+    resolution, the count / dtype / op arguments and the stream hand-over.  N > 1 is covered by bench.py under torch.distributed.run."""
+    import ctypes as C
+    import os
+    from oracle import mudpt_oracle as O
+    from tests.helpers import GoldenCase
+    from tests.test_model_gpu import build
+    rccl = None
+    for cand in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = C.CDLL(cand)
+            break
+        except OSError:
+            continue
+    assert rccl is not None, "RCCL not found"
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    case = GoldenCase("mudpt_tiny")
+    m = build(case, "fp16")
+    m.forward_backward(case.images, case.labels)
+    torch.cuda.synchronize()
+    before = m.flat_grads.clone()
+    assert before.abs().sum().item() > 0
+    from mudpt_amd import capi
+    capi.check(m.lib.mudpt_allreduce_grads(m._h, comm, m._stream()), "allreduce_grads")
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_grads, before)
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+    m.close()

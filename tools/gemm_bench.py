@@ -1,7 +1,7 @@
 """GEMM micro-benchmark through the C ABI (GPU box): the model's GEMM shapes at B = 256, random operands.
 
     python tools/gemm_bench.py [--dtype bf16] [--variants 0,1] [--rounds 5]
-Variants are selected with mudpt_debug_set("gemm_variant", v) and interleaved in one process (A/B rule)."""
+Variants are selected with mudpt_gemm's variant argument and interleaved in one process (A/B rule)."""
 import argparse
 import ctypes as C
 import os
@@ -54,20 +54,19 @@ def main():
         out1 = torch.empty(M, N, device="cuda", dtype=tt) if epi == 1 else None
         aux = torch.randn(M, N, device="cuda").to(torch.float32 if epi == 2 else tt) if epi in (2, 3) else None
 
-        def run():
+        def run(v=0):
             rc = lib.mudpt_gemm(dt, epi, M, N, K, P(A), K, P(B), K, P(bias) if epi != 3 else None, P(out0), N, P(out1), N if out1 is not None else 0,
-                                P(aux), N if aux is not None else 0, 0, 0, None, None)
+                                P(aux), N if aux is not None else 0, 0, 0, None, v, None)
             assert rc == 0, lib.mudpt_last_error()
         best = {v: 1e9 for v in variants}
         for r in range(a.rounds):
             for v in variants:
-                capi.check(lib.mudpt_debug_set(b"gemm_variant", v))
-                run()
+                run(v)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.iters):
-                    run()
+                    run(v)
                 e1.record()
                 torch.cuda.synchronize()
                 best[v] = min(best[v], e0.elapsed_time(e1) / a.iters)
