@@ -136,6 +136,12 @@ int mudpt_model_set(mudpt_model* m, const char* name, int32_t value);
  * the number of launches since the last enable / read. */
 int mudpt_profile_enable(mudpt_model* m, int32_t enable);
 int mudpt_profile_read(mudpt_model* m, double* gemm_ms, double* gemm_flop, int64_t* launches);
+/* The same per kernel class (arrays of MUDPT_PROF_CLASSES entries): 0 the persistent MFMA GEMM (work = algorithmic FLOPs), 1 / 2
+ * LayerNorm forward / backward, 3 / 4 attention forward / backward (dQ + dK/dV kernels together) of the vision tower (work =
+ * algorithmic HBM bytes: every operand read once, every result written once).  executed_flop (may be NULL): MFMA FLOPs actually
+ * executed by all GEMM and attention launches of both towers. */
+#define MUDPT_PROF_CLASSES 5
+int mudpt_profile_read_classes(mudpt_model* m, double* ms, double* work, int64_t* launches, double* executed_flop);
 
 /* ---- single kernels, exported for parity tests (all pointers device memory) ---------------------------- */
 /* epilogues: 0 store T | 1 bias+QuickGELU (out0 = u, out1 = gelu(u)) | 2 f32 out0 = aux + acc + bias |

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mudpt_model_set": (_i32, [_vp, C.c_char_p, _i32]),
     "mudpt_profile_enable": (_i32, [_vp, _i32]),
     "mudpt_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mudpt_profile_read_classes": (_i32, [_vp, C.POINTER(C.c_double * 5), C.POINTER(C.c_double * 5), C.POINTER(C.c_int64 * 5), C.POINTER(C.c_double)]),
     "mudpt_gemm": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32,
                           _i32, _i32, _vp, _i32, _vp]),
     "mudpt_layernorm_fwd": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),

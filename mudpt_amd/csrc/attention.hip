@@ -737,21 +737,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_tiled_kernel(AttnArgs p, int
 }
 
 template <typename T, bool BWD>
-static int tiled_launch(const AttnArgs& a, hipStream_t s) {
+static int tiled_launch(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
+    const LaunchProf p1{prof ? prof->start : nullptr, nullptr}, p2{nullptr, prof ? prof->stop : nullptr};
     const int nsb = (a.L + 63) / 64;
     const size_t nwg = (size_t)a.B * a.H * nsb;
     ARG_CHECK(nwg < 0x7fffffffull, "attention: too many workgroups (%zu)", nwg);
     const dim3 grid((unsigned)nwg), block(256);
     if (!BWD) {
-        if (a.causal) hipLaunchKernelGGL((attn_fwd_tiled_kernel<T, true>), grid, block, 0, s, a, nsb);
-        else hipLaunchKernelGGL((attn_fwd_tiled_kernel<T, false>), grid, block, 0, s, a, nsb);
+        if (a.causal) MUDPT_LAUNCH((attn_fwd_tiled_kernel<T, true>), grid, block, 0, s, prof, a, nsb);
+        else MUDPT_LAUNCH((attn_fwd_tiled_kernel<T, false>), grid, block, 0, s, prof, a, nsb);
     } else {
         if (a.causal) {
-            hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<T, true>), grid, block, 0, s, a, (const void*)a.out, nsb);
-            hipLaunchKernelGGL((attn_bwd_dkv_tiled_kernel<T, true>), grid, block, 0, s, a, nsb);
+            MUDPT_LAUNCH((attn_bwd_dq_tiled_kernel<T, true>), grid, block, 0, s, &p1, a, (const void*)a.out, nsb);
+            MUDPT_LAUNCH((attn_bwd_dkv_tiled_kernel<T, true>), grid, block, 0, s, &p2, a, nsb);
         } else {
-            hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<T, false>), grid, block, 0, s, a, (const void*)a.out, nsb);
-            hipLaunchKernelGGL((attn_bwd_dkv_tiled_kernel<T, false>), grid, block, 0, s, a, nsb);
+            MUDPT_LAUNCH((attn_bwd_dq_tiled_kernel<T, false>), grid, block, 0, s, &p1, a, (const void*)a.out, nsb);
+            MUDPT_LAUNCH((attn_bwd_dkv_tiled_kernel<T, false>), grid, block, 0, s, &p2, a, nsb);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -778,20 +779,20 @@ static int set_lds(K kern, int bytes) {
 }
 
 template <typename T, int NC, bool CAUSAL>
-static int fwd_pair_cfg(const AttnArgs& a, hipStream_t s) {
+static int fwd_pair_cfg(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
     constexpr int lds = 2 * NC * 32 * RS * 2 + NC * 32 * 4;
     auto kern = attn_fwd_pair_kernel<T, NC, CAUSAL>;
     static PerDevice pd;
     const int dev = current_device();
     if (!pd.done[dev]) { if (int e = set_lds(kern, lds)) return e; pd.done[dev] = true; }
-    hipLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(NC * 64), lds, s, a);
+    MUDPT_LAUNCH(kern, dim3(a.B * a.H), dim3(NC * 64), lds, s, prof, a);
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
 }
 
 template <typename T, int NC, bool CAUSAL>
-static int fwd_cfg(const AttnArgs& a, hipStream_t s) {
-    if constexpr (CAUSAL) return fwd_pair_cfg<T, NC, CAUSAL>(a, s);
+static int fwd_cfg(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
+    if constexpr (CAUSAL) return fwd_pair_cfg<T, NC, CAUSAL>(a, s, prof);
     constexpr int lds = 4 * NC * 32 * 128 + NC * 32 * 4;  // two (K, V) image pairs + the key mask
     auto kern = attn_fwd_kernel<T, NC, CAUSAL>;
     static PerDevice pd;
@@ -804,13 +805,14 @@ static int fwd_cfg(const AttnArgs& a, hipStream_t s) {
     const int ncu = pd.ncu[dev];
     const int npairs = a.B * a.H, per_cu = 163840 / lds > 0 ? 163840 / lds : 1;
     const int cap = ncu * (per_cu * 2 * NC <= 32 ? per_cu : 32 / (2 * NC));  // resident workgroups: LDS and the 32-wave limit
-    hipLaunchKernelGGL(kern, dim3(npairs < cap ? npairs : cap), dim3(NC * 128), lds, s, a, npairs);
+    MUDPT_LAUNCH(kern, dim3(npairs < cap ? npairs : cap), dim3(NC * 128), lds, s, prof, a, npairs);
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
 }
 
 template <typename T, int NC, bool CAUSAL>
-static int bwd_cfg(const AttnArgs& a, hipStream_t s) {
+static int bwd_cfg(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
+    const LaunchProf p1{prof ? prof->start : nullptr, nullptr}, p2{nullptr, prof ? prof->stop : nullptr};
     constexpr int lds1 = 2 * NC * 32 * RS * 2 + NC * 32 * 4;
     constexpr int lds2 = 2 * NC * 32 * RS * 2 + 2 * NC * 32 * 4;
     auto k1 = attn_bwd_dq_kernel<T, NC, CAUSAL>;
@@ -822,20 +824,20 @@ static int bwd_cfg(const AttnArgs& a, hipStream_t s) {
         if (int e = set_lds(k2, lds2)) return e;
         pd.done[dev] = true;
     }
-    hipLaunchKernelGGL(k1, dim3(a.B * a.H), dim3(NC * 64), lds1, s, a, (const void*)a.out);
-    hipLaunchKernelGGL(k2, dim3(a.B * a.H), dim3(NC * 64), lds2, s, a);
+    MUDPT_LAUNCH(k1, dim3(a.B * a.H), dim3(NC * 64), lds1, s, &p1, a, (const void*)a.out);
+    MUDPT_LAUNCH(k2, dim3(a.B * a.H), dim3(NC * 64), lds2, s, &p2, a);
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
 }
 
 template <typename T, bool BWD>
-static int dispatch(const AttnArgs& a, hipStream_t s) {
-    if (a.L > 224) return tiled_launch<T, BWD>(a, s);  // the other operand streams through 64-row stages
+static int dispatch(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
+    if (a.L > 224) return tiled_launch<T, BWD>(a, s, prof);  // the other operand streams through 64-row stages
     const int nc = attn_padded_len(a.L) / 32;
 #define MUDPT_ATTN_CASE(N)                                                                     \
     case N:                                                                                    \
-        if (a.causal) return BWD ? bwd_cfg<T, N, true>(a, s) : fwd_cfg<T, N, true>(a, s);      \
-        return BWD ? bwd_cfg<T, N, false>(a, s) : fwd_cfg<T, N, false>(a, s);
+        if (a.causal) return BWD ? bwd_cfg<T, N, true>(a, s, prof) : fwd_cfg<T, N, true>(a, s, prof);      \
+        return BWD ? bwd_cfg<T, N, false>(a, s, prof) : fwd_cfg<T, N, false>(a, s, prof);
     switch (nc) {
         MUDPT_ATTN_CASE(1)
         MUDPT_ATTN_CASE(2)
@@ -850,18 +852,18 @@ static int dispatch(const AttnArgs& a, hipStream_t s) {
     return MUDPT_ERR_ARG;
 }
 
-int launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
+int launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
     if (int e = check(a, false)) return e;
-    if (dtype == DT_BF16) return dispatch<BF16, false>(a, s);
-    if (dtype == DT_F16) return dispatch<F16, false>(a, s);
+    if (dtype == DT_BF16) return dispatch<BF16, false>(a, s, prof);
+    if (dtype == DT_F16) return dispatch<F16, false>(a, s, prof);
     set_error("attention: unknown dtype %d", dtype);
     return MUDPT_ERR_ARG;
 }
 
-int launch_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s) {
+int launch_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
     if (int e = check(a, true)) return e;
-    if (dtype == DT_BF16) return dispatch<BF16, true>(a, s);
-    if (dtype == DT_F16) return dispatch<F16, true>(a, s);
+    if (dtype == DT_BF16) return dispatch<BF16, true>(a, s, prof);
+    if (dtype == DT_F16) return dispatch<F16, true>(a, s, prof);
     set_error("attention: unknown dtype %d", dtype);
     return MUDPT_ERR_ARG;
 }

@@ -1,6 +1,7 @@
 // Shared device/host definitions for the MuDPT gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace mudpt {
@@ -84,6 +85,17 @@ struct PerDevice {
     bool done[64] = {};
     int ncu[64] = {};
 };
+// Optional HIP events that ride on a kernel's own dispatch packet (measurement legs of bench.py): start is recorded when the kernel
+// begins, stop when it ends; no marker packets between kernels.
+struct LaunchProf {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+#define MUDPT_LAUNCH(kern, grid, block, lds, stream, prof, ...)                                                          \
+    do {                                                                                                                 \
+        const mudpt::LaunchProf* _lp = (prof);                                                                           \
+        if (_lp && (_lp->start || _lp->stop)) hipExtLaunchKernelGGL(kern, grid, block, lds, stream, _lp->start, _lp->stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                             \
+    } while (0)
 inline int current_device() {
     int d = 0;
     (void)hipGetDevice(&d);

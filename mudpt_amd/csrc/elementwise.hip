@@ -381,9 +381,16 @@ __global__ __launch_bounds__(256) void pair_dtxt_kernel(const float* __restrict_
 
 // a.txt / txt_n / txt_inv / dtxt have B * C rows (row i * C + c); a.dimg is not produced (the image encoder is frozen and
 // meta_net's input is a constant of the step: nothing upstream of the image features trains, trainers/cocoop.py:222-226)
+int launch_mean(const float* v, int n, float* out, hipStream_t s) {
+    ARG_CHECK(v && out && n > 0, "mean: bad arguments");
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, v, n, out);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
+// the image features are normalised by the caller (they also feed meta_net): a.img_n / a.img_inv are inputs here
 int launch_pair_head_fwd(const HeadArgs& a, hipStream_t s) {
     if (int e = check_head(a)) return e;
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a.img, a.img_n, a.img_inv, a.B, a.e);
     hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((a.B * a.C + 3) / 4), dim3(256), 0, s, a.txt, a.txt_n, a.txt_inv, a.B * a.C, a.e);
     hipLaunchKernelGGL(pair_logits_kernel, dim3((a.B * a.C + 3) / 4), dim3(256), 0, s, a.img_n, a.txt_n, a.logits, a.B, a.C, a.e, a.scale);
     HIP_TRY(hipGetLastError());
@@ -393,8 +400,9 @@ int launch_pair_head_fwd(const HeadArgs& a, hipStream_t s) {
 int launch_pair_head_bwd(const HeadArgs& a, hipStream_t s) {
     if (int e = check_head(a)) return e;
     ARG_CHECK(a.labels && a.loss && a.dlogits && a.row_loss && a.dtxt, "pair head bwd: null operand");
-    hipLaunchKernelGGL(ce_rows_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a.logits, a.labels, a.row_loss, a.dlogits, a.B, a.C, a.grad_scale / a.B);
-    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, a.row_loss, a.B, a.loss);
+    const int Bt = a.B_total > 0 ? a.B_total : a.B;  // chunked over the images: the mean is over the whole batch, taken by the caller
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a.logits, a.labels, a.row_loss, a.dlogits, a.B, a.C, a.grad_scale / Bt);
+    if (a.B_total <= 0) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, a.row_loss, a.B, a.loss);
     hipLaunchKernelGGL(pair_dtxt_kernel, dim3(a.B * a.C), dim3(128), 0, s, a.dlogits, a.img_n, a.dtxt, a.B, a.C, a.e, a.scale);
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((a.B * a.C + 3) / 4), dim3(256), 0, s, a.dtxt, a.txt_n, a.txt_inv, a.B * a.C, a.e);
     HIP_TRY(hipGetLastError());

@@ -61,7 +61,7 @@ struct LnFwdArgs {
     float* xout = nullptr; int ldxout = 0;
     const float* ov_rows = nullptr; int ov_row0 = 0, ov_n = 0, ov_L = 1;
 };
-int launch_ln_fwd(int dtype, const LnFwdArgs& a, hipStream_t s);
+int launch_ln_fwd(int dtype, const LnFwdArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);
 
 struct LnBwdArgs {
     const void* dy = nullptr; int lddy = 0; bool dy_f32 = false;  // grad of LN output (T or fp32), compact rows
@@ -76,7 +76,7 @@ struct LnBwdArgs {
     bool by_token = false;  // dy / mean / rstd rows are indexed by the token row (row_index[r]) instead of r
     bool stats_by_token = false;  // only mean / rstd are indexed by the token row; dy stays compact (row r)
 };
-int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s);
+int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // Attention on packed qkv [B, L, 3*H*64] (q | k | v, heads contiguous inside each third), head dim 64.
@@ -96,8 +96,8 @@ struct AttnArgs {
     int B = 0, L = 0, H = 0; bool causal = false;
 };
 int attn_padded_len(int L);
-int launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s);
-int launch_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s);
+int launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);
+int launch_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);  // prof spans both kernels
 
 // ------------------------------------------------------------------------------------------------
 // Small / HBM-bound helpers
@@ -141,12 +141,14 @@ struct HeadArgs {
     float* txt_inv = nullptr;     // [C]
     float grad_scale = 1.f;       // dlogits = (softmax - onehot) * grad_scale / B  (the caller folds loss scaling in here)
     int B = 0, C = 0, e = 0;
+    int B_total = 0;              // pair head, chunked over the images: the batch the mean is taken over (0 = B); then the caller computes the loss (launch_mean)
 };
 int launch_head_fwd(const HeadArgs& a, hipStream_t s);
 int launch_head_bwd(const HeadArgs& a, hipStream_t s);
 // CoCoOp (trainers/cocoop.py): per-image text features.  txt / txt_n / txt_inv / dtxt have B * C rows (row i * C + c).
 int launch_pair_head_fwd(const HeadArgs& a, hipStream_t s);
 int launch_pair_head_bwd(const HeadArgs& a, hipStream_t s);  // loss, dlogits, dtxt (gradient of the raw text features)
+int launch_mean(const float* v, int n, float* out, hipStream_t s);  // out[0] = mean(v) in a fixed order
 // text-tower input of every (image, class) pair: class prompt + positional embedding, context rows = ctx + meta_net(image) + pos
 int launch_cocoop_prompts(float* x0, const float* emb_pos, const float* ctx, const float* bias, const float* pos, int B, int C, int L, int d, int n, hipStream_t s);
 // d bias[i] = scale * sum over the classes and the n context rows of the text-input gradient (fp32 dx or its T copy)

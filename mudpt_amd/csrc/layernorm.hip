@@ -139,17 +139,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     }
 }
 
-int launch_ln_fwd(int dtype, const LnFwdArgs& a, hipStream_t s) {
+int launch_ln_fwd(int dtype, const LnFwdArgs& a, hipStream_t s, const LaunchProf* prof) {
     ARG_CHECK(a.x && a.gamma && a.beta && a.out, "ln_fwd: null operand");
     ARG_CHECK(a.rows > 0 && a.d > 0 && a.d % 4 == 0 && a.d <= 256 * LN_MAXV, "ln_fwd: bad shape rows=%d d=%d", a.rows, a.d);
     ARG_CHECK(a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.ldx >= a.d && a.ldo >= a.d, "ln_fwd: bad strides %d/%d", a.ldx, a.ldo);
     const dim3 grid((a.rows + 3) / 4), block(256);
     if (dtype == DT_BF16) {
-        if (a.out_f32) hipLaunchKernelGGL((ln_fwd_kernel<BF16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((ln_fwd_kernel<BF16, false>), grid, block, 0, s, a);
+        if (a.out_f32) MUDPT_LAUNCH((ln_fwd_kernel<BF16, true>), grid, block, 0, s, prof, a);
+        else MUDPT_LAUNCH((ln_fwd_kernel<BF16, false>), grid, block, 0, s, prof, a);
     } else if (dtype == DT_F16) {
-        if (a.out_f32) hipLaunchKernelGGL((ln_fwd_kernel<F16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((ln_fwd_kernel<F16, false>), grid, block, 0, s, a);
+        if (a.out_f32) MUDPT_LAUNCH((ln_fwd_kernel<F16, true>), grid, block, 0, s, prof, a);
+        else MUDPT_LAUNCH((ln_fwd_kernel<F16, false>), grid, block, 0, s, prof, a);
     } else {
         set_error("ln_fwd: unknown dtype %d", dtype);
         return MUDPT_ERR_ARG;
@@ -158,18 +158,18 @@ int launch_ln_fwd(int dtype, const LnFwdArgs& a, hipStream_t s) {
     return MUDPT_OK;
 }
 
-int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s) {
+int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s, const LaunchProf* prof) {
     ARG_CHECK(a.dy && a.x && a.mean && a.rstd && a.gamma && (a.dx || a.dx_lp), "ln_bwd: null operand");
     ARG_CHECK(!(a.dres && a.dres_lp), "ln_bwd: dres and dres_lp are exclusive");
     ARG_CHECK(a.rows > 0 && a.d > 0 && a.d % 4 == 0 && a.d <= 256 * LN_MAXV, "ln_bwd: bad shape rows=%d d=%d", a.rows, a.d);
     ARG_CHECK(a.ldx % 4 == 0 && a.lddy % 4 == 0 && a.lddx % 4 == 0, "ln_bwd: strides must be multiples of 4");
     const dim3 grid((a.rows + 3) / 4), block(256);
     if (dtype == DT_BF16) {
-        if (a.dy_f32) hipLaunchKernelGGL((ln_bwd_kernel<BF16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((ln_bwd_kernel<BF16, false>), grid, block, 0, s, a);
+        if (a.dy_f32) MUDPT_LAUNCH((ln_bwd_kernel<BF16, true>), grid, block, 0, s, prof, a);
+        else MUDPT_LAUNCH((ln_bwd_kernel<BF16, false>), grid, block, 0, s, prof, a);
     } else if (dtype == DT_F16) {
-        if (a.dy_f32) hipLaunchKernelGGL((ln_bwd_kernel<F16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((ln_bwd_kernel<F16, false>), grid, block, 0, s, a);
+        if (a.dy_f32) MUDPT_LAUNCH((ln_bwd_kernel<F16, true>), grid, block, 0, s, prof, a);
+        else MUDPT_LAUNCH((ln_bwd_kernel<F16, false>), grid, block, 0, s, prof, a);
     } else {
         set_error("ln_bwd: unknown dtype %d", dtype);
         return MUDPT_ERR_ARG;

@@ -98,6 +98,7 @@ struct Tower {
     const int* head_rows = nullptr;  // [nseq * n_ctx] token rows of the prompt tokens
     int head_n = 0;                  // rows per sequence
     void *hd_dqkv = nullptr, *hd_h = nullptr;  // T [max_seq * n_ctx, 3 d], [max_seq * n_ctx, d]
+    std::vector<void*> act_allocs;  // activation / scratch buffers (sized for max_seq sequences of L rows): re-made when L changes
 };
 
 }  // namespace mudpt
@@ -151,17 +152,40 @@ struct mudpt_model {
     // per-handle tuning knobs (mudpt_model_set): nothing here is process-global, two models in one process do not interfere
     int gemm_variant = 0;
     bool txt_trim = true;  // run the text tower on positions 0..max(eot) only (read by mudpt_set_class_prompts)
+    int cocoop_chunk = 0;  // knob: cap on the images per text-tower pass (0 = as many as the memory budget allows)
+    int txt_chunk = 1;     // CoCoOp: images per text-tower pass, set by mudpt_set_class_prompts
     bool any_weight_set = false;
     // side stream for the text tower (forks after the prompt learner / head backward, joins before the head /
     // prompt-learner backward)
     hipStream_t s2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork_b = nullptr, ev_join_b = nullptr;
-    // optional HIP-event timing of the MFMA GEMM launches (bench.py's roofline leg)
+    // optional HIP-event timing of the big vision-tower launches (bench.py's roofline legs), by kernel class
     bool prof = false;
     std::vector<hipEvent_t> ev;  // pairs
     size_t ev_used = 0;
-    std::vector<double> ev_flop;
+    struct ProfRec { int cls; double work; };
+    std::vector<ProfRec> ev_rec;  // one per event pair: class and algorithmic work (FLOPs for the GEMM, bytes for the HBM-bound kernels)
+    double exec_flop = 0;         // executed MFMA FLOPs (every GEMM and attention launch of both towers) since profile_enable / read
 };
+enum ProfClass : int { PC_GEMM = 0, PC_LN_FWD = 1, PC_LN_BWD = 2, PC_ATTN_FWD = 3, PC_ATTN_BWD = 4, PC_COUNT = 5 };
+
+// Next event pair for a bracketed launch of class cls (nullptr-filled when profiling is off).
+static int prof_next(mudpt_model* m, int cls, double work, LaunchProf* out) {
+    *out = LaunchProf();
+    if (!m->prof) return MUDPT_OK;
+    if (m->ev_used + 2 > m->ev.size()) {
+        for (int i = 0; i < 512; ++i) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            m->ev.push_back(e);
+        }
+    }
+    out->start = m->ev[m->ev_used];
+    out->stop = m->ev[m->ev_used + 1];
+    m->ev_used += 2;
+    m->ev_rec.push_back({cls, work});
+    return MUDPT_OK;
+}
 
 // Every MFMA GEMM of the path goes through here; with profiling on, the launch is bracketed by HIP events on
 // the launch stream and its algorithmic FLOPs (2 M N K) are recorded.
@@ -170,20 +194,43 @@ static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s) 
     // tower's small GEMMs run on the side stream, where an event pair would mostly measure queueing behind the other stream.
     GemmOpts o;
     o.variant = m->gemm_variant;
+    if (m->prof) m->exec_flop += 2.0 * a.M * a.N * a.K;
     if (!m->prof || !gemm_uses_pp(epi, a, o.variant)) return launch_gemm(m->dtype, epi, a, s, o);
-    if (m->ev_used + 2 > m->ev.size()) {
-        for (int i = 0; i < 512; ++i) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreate(&e));
-            m->ev.push_back(e);
-        }
-    }
-    o.ev_start = m->ev[m->ev_used];
-    o.ev_stop = m->ev[m->ev_used + 1];
-    const int rc = launch_gemm(m->dtype, epi, a, s, o);
-    m->ev_used += 2;
-    m->ev_flop.push_back(2.0 * a.M * a.N * a.K);
-    return rc;
+    LaunchProf lp;
+    if (int rc = prof_next(m, PC_GEMM, 2.0 * a.M * a.N * a.K, &lp)) return rc;
+    o.ev_start = lp.start;
+    o.ev_stop = lp.stop;
+    return launch_gemm(m->dtype, epi, a, s, o);
+}
+
+// LayerNorm / attention launches of the path.  The big vision-tower ones (main stream) are bracketed when profiling is on; their
+// work figure is the ALGORITHMIC HBM bytes of the launch: every operand read once, every result written once.
+static bool prof_big(const mudpt_model* m, const Tower& t, int rows) { return m->prof && &t == &m->vis && rows >= 4096; }
+static int ln_fwd_call(mudpt_model* m, const Tower& t, const LnFwdArgs& a, hipStream_t s) {
+    if (!prof_big(m, t, a.rows)) return launch_ln_fwd(m->dtype, a, s);
+    const double per_elem = 4.0 + (a.add ? 4.0 : 0.0) + (a.add_lp ? 2.0 : 0.0) + (a.xout ? 4.0 : 0.0) + (a.out_f32 ? 4.0 : 2.0) + (a.out_lo ? 2.0 : 0.0);
+    LaunchProf lp;
+    if (int rc = prof_next(m, PC_LN_FWD, per_elem * a.rows * a.d, &lp)) return rc;
+    return launch_ln_fwd(m->dtype, a, s, &lp);
+}
+static int ln_bwd_call(mudpt_model* m, const Tower& t, const LnBwdArgs& a, hipStream_t s) {
+    if (!prof_big(m, t, a.rows)) return launch_ln_bwd(m->dtype, a, s);
+    const double per_elem = (a.dy_f32 ? 4.0 : 2.0) + 4.0 + (a.dres ? 4.0 : 0.0) + (a.dres_lp ? 2.0 : 0.0) + (a.dx ? 4.0 : 0.0) + (a.dx_lp ? 2.0 : 0.0);
+    LaunchProf lp;
+    if (int rc = prof_next(m, PC_LN_BWD, per_elem * a.rows * a.d, &lp)) return rc;
+    return launch_ln_bwd(m->dtype, a, s, &lp);
+}
+static int attn_call(mudpt_model* m, const Tower& t, const AttnArgs& a, bool bwd, hipStream_t s) {
+    // executed MFMA FLOPs: forward S = QK^T and PV (2 products of 2 L^2 64 each per head); backward 7 products (dQ sweep: S, dP, dQ;
+    // dK/dV sweep: S, dP, dV, dK); the causal tower does about half of each
+    const double prod = 2.0 * a.L * (double)a.L * 64.0 * a.H * a.B * (a.causal ? 0.5 : 1.0);
+    if (m->prof && !a.sel_rows) m->exec_flop += (bwd ? 7.0 : 2.0) * prod;
+    if (!prof_big(m, t, a.B * a.L) || a.sel_rows) return bwd ? launch_attn_bwd(m->dtype, a, s) : launch_attn_fwd(m->dtype, a, s);
+    // algorithmic bytes: forward reads q, k, v and writes o (+ its low half in split mode); backward reads q, k, v, o, do and writes dq, dk, dv
+    const double tok = (double)a.B * a.L * a.H * 128.0;
+    LaunchProf lp;
+    if (int rc = prof_next(m, bwd ? PC_ATTN_BWD : PC_ATTN_FWD, bwd ? 8.0 * tok : (4.0 + (a.out_lo ? 1.0 : 0.0)) * tok, &lp)) return rc;
+    return bwd ? launch_attn_bwd(m->dtype, a, s, &lp) : launch_attn_fwd(m->dtype, a, s, &lp);
 }
 
 static const char* kParamNames[10] = {
@@ -222,13 +269,10 @@ static int dev_alloc(mudpt_model* m, void** out, size_t bytes) {
         if (int _e = dev_alloc(m, (void**)&(ptr), (size_t)(bytes))) return _e; \
     } while (0)
 
-static int alloc_tower(mudpt_model* m, Tower& t, int d, int layers, int heads, int L, int max_seq, bool causal, int prompt_row0, bool split = false) {
+// Frozen weights of a tower (device copies; filled by mudpt_set_weight).
+static int alloc_tower_weights(mudpt_model* m, Tower& t, int d, int layers, int heads, bool causal, int prompt_row0, bool split) {
     t.split = split;
-    const size_t sp = split ? 2 : 1;
-    t.d = d; t.layers = layers; t.heads = heads; t.L = L; t.max_seq = max_seq; t.causal = causal;
-    t.prompt_row0 = prompt_row0;
-    t.Lp = attn_padded_len(L);
-    const size_t M = (size_t)max_seq * L;
+    t.d = d; t.layers = layers; t.heads = heads; t.causal = causal; t.prompt_row0 = prompt_row0;
     t.w.resize(layers);
     t.a.resize(layers);
     for (int i = 0; i < layers; ++i) {
@@ -243,23 +287,54 @@ static int alloc_tower(mudpt_model* m, Tower& t, int d, int layers, int heads, i
         }
         ALLOC(w.b_in, 3 * d * 4); ALLOC(w.b_out, d * 4); ALLOC(w.b_fc, 4 * d * 4); ALLOC(w.b_proj, d * 4);
         ALLOC(w.ln1_g, d * 4); ALLOC(w.ln1_b, d * 4); ALLOC(w.ln2_g, d * 4); ALLOC(w.ln2_b, d * 4);
-        BlockAct& a = t.a[i];
-        ALLOC(a.x_in, M * d * 4); ALLOC(a.x_mid, M * d * 4);
-        ALLOC(a.mean1, M * 4); ALLOC(a.rstd1, M * 4); ALLOC(a.mean2, M * 4); ALLOC(a.rstd2, M * 4);
-        ALLOC(a.qkv, M * 3 * d * 2); ALLOC(a.attn, M * d * 2 * sp); ALLOC(a.u, M * 4 * d * 2);
-        ALLOC(a.lse, (size_t)max_seq * heads * t.Lp * 4);
     }
-    ALLOC(t.h, M * d * 2 * sp); ALLOC(t.g, M * 4 * d * 2 * sp);
-    ALLOC(t.dx, M * d * 4); ALLOC(t.dx_lp, M * d * 2);
-    ALLOC(t.dattn, M * d * 2); ALLOC(t.dqkv, M * 3 * d * 2);
-    ALLOC(t.delta, (size_t)max_seq * heads * t.Lp * 4);
-    ALLOC(t.upd, M * d * 4);
+    return MUDPT_OK;
+}
+
+// Bytes of activations + scratch per token row of a tower (what alloc_tower_acts takes per row; sizes the CoCoOp chunk).
+static size_t tower_bytes_per_row(const Tower& t) {
+    const size_t d = t.d, sp = 2;  // split operands counted always (upper bound)
+    const size_t per_layer = d * 4 * 2 + d * 3 * 2 + d * 2 * sp + d * 4 * 2 + 16 + (size_t)t.heads * 4 * 2;
+    const size_t shared = d * 2 * sp + d * 4 * 2 * sp + d * 4 + d * 2 + d * 2 + d * 3 * 2 + d * 4 + (size_t)t.heads * 4 * 2;
+    return per_layer * t.layers + shared;
+}
+
+// Activations saved for the backward + scratch, for max_seq sequences of L rows.  The vision tower's are made at create; the
+// text tower's when the class prompts (and with them its trimmed length) are known -- and again if those change.
+static int alloc_tower_acts(mudpt_model* m, Tower& t, int L, int max_seq) {
+    for (void* p : t.act_allocs) (void)hipFree(p);
+    t.act_allocs.clear();
+#define ALLOC_T(ptr, bytes)                                                      \
+    do {                                                                         \
+        void* _p = nullptr;                                                      \
+        HIP_TRY(hipMalloc(&_p, (size_t)(bytes) ? (size_t)(bytes) : 16));         \
+        t.act_allocs.push_back(_p);                                              \
+        *(void**)&(ptr) = _p;                                                    \
+    } while (0)
+    const size_t sp = t.split ? 2 : 1;
+    const int d = t.d, heads = t.heads;
+    t.L = L; t.max_seq = max_seq;
+    t.Lp = attn_padded_len(L);
+    const size_t M = (size_t)max_seq * L;
+    for (int i = 0; i < t.layers; ++i) {
+        BlockAct& a = t.a[i];
+        ALLOC_T(a.x_in, M * d * 4); ALLOC_T(a.x_mid, M * d * 4);
+        ALLOC_T(a.mean1, M * 4); ALLOC_T(a.rstd1, M * 4); ALLOC_T(a.mean2, M * 4); ALLOC_T(a.rstd2, M * 4);
+        ALLOC_T(a.qkv, M * 3 * d * 2); ALLOC_T(a.attn, M * d * 2 * sp); ALLOC_T(a.u, M * 4 * d * 2);
+        ALLOC_T(a.lse, (size_t)max_seq * heads * t.Lp * 4);
+    }
+    ALLOC_T(t.h, M * d * 2 * sp); ALLOC_T(t.g, M * 4 * d * 2 * sp);
+    ALLOC_T(t.dx, M * d * 4); ALLOC_T(t.dx_lp, M * d * 2);
+    ALLOC_T(t.dattn, M * d * 2); ALLOC_T(t.dqkv, M * 3 * d * 2);
+    ALLOC_T(t.delta, (size_t)max_seq * heads * t.Lp * 4);
+    ALLOC_T(t.upd, M * d * 4);
     const size_t S = (size_t)max_seq;
-    ALLOC(t.xin_sel, S * d * 4); ALLOC(t.xmid_sel, S * d * 4); ALLOC(t.xout_sel, S * d * 4);
-    ALLOC(t.attn_sel, S * d * 2 * sp); ALLOC(t.h_sel, S * d * 2 * sp); ALLOC(t.u_sel, S * 4 * d * 2); ALLOC(t.g_sel, S * 4 * d * 2 * sp); ALLOC(t.dattn_sel, S * d * 2);
-    ALLOC(t.dsel, S * d * 4); ALLOC(t.dsel_lp, S * d * 2);
+    ALLOC_T(t.xin_sel, S * d * 4); ALLOC_T(t.xmid_sel, S * d * 4); ALLOC_T(t.xout_sel, S * d * 4);
+    ALLOC_T(t.attn_sel, S * d * 2 * sp); ALLOC_T(t.h_sel, S * d * 2 * sp); ALLOC_T(t.u_sel, S * 4 * d * 2); ALLOC_T(t.g_sel, S * 4 * d * 2 * sp); ALLOC_T(t.dattn_sel, S * d * 2);
+    ALLOC_T(t.dsel, S * d * 4); ALLOC_T(t.dsel_lp, S * d * 2);
     t.head_n = m->cfg.n_ctx;
-    ALLOC(t.hd_dqkv, S * t.head_n * 3 * d * 2); ALLOC(t.hd_h, S * t.head_n * d * 2);
+    ALLOC_T(t.hd_dqkv, S * t.head_n * 3 * d * 2); ALLOC_T(t.hd_h, S * t.head_n * d * 2);
+#undef ALLOC_T
     return MUDPT_OK;
 }
 
@@ -299,8 +374,12 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     const int dv = c->v_width, dt = c->t_width, e = c->embed_dim, n = c->n_ctx, D1 = m->cfg.depth - 1, B = c->max_batch, C = c->n_cls;
     const int TS = cocoop ? B * C : C;  // text sequences per step: one per (image, class) pair in CoCoOp (trainers/cocoop.py:187-194)
     auto fail = [&](int code) { mudpt_destroy(m); return code; };
-    if (int r = alloc_tower(m, m->vis, dv, c->v_layers, c->v_heads, Lv, B, false, cocoop ? Lv : Lv - n)) return fail(r);
-    if (int r = alloc_tower(m, m->txt, dt, c->t_layers, c->t_heads, c->ctx_len, TS, true, 1, c->dtype == MUDPT_F16)) return fail(r);
+    if (int r = alloc_tower_weights(m, m->vis, dv, c->v_layers, c->v_heads, false, cocoop ? Lv : Lv - n, false)) return fail(r);
+    if (int r = alloc_tower_acts(m, m->vis, Lv, B)) return fail(r);
+    // the text tower's activations are sized by mudpt_set_class_prompts: its trimmed length (max(eot) + 1 of ctx_len positions) and, for
+    // CoCoOp, the number of images whose B * C prompts fit the memory budget at once are only known there
+    if (int r = alloc_tower_weights(m, m->txt, dt, c->t_layers, c->t_heads, true, 1, c->dtype == MUDPT_F16)) return fail(r);
+    m->txt.L = c->ctx_len; m->txt.Lp = attn_padded_len(c->ctx_len);
     auto body = [&]() -> int {
         const int K0 = (3 * c->patch * c->patch + 63) / 64 * 64;  // conv-as-GEMM K, zero-padded to the GEMM's granularity (ViT-L/14: 588 -> 640)
         ALLOC(m->conv_w, (size_t)dv * K0 * 2);
@@ -372,6 +451,8 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
 extern "C" int mudpt_destroy(mudpt_model* m) {
     if (!m) return MUDPT_OK;
     for (void* p : m->allocs) (void)hipFree(p);
+    for (Tower* t : {&m->vis, &m->txt})
+        for (void* p : t->act_allocs) (void)hipFree(p);
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : {m->ev_fork, m->ev_join, m->ev_fork_b, m->ev_join_b})
         if (e) (void)hipEventDestroy(e);
@@ -497,11 +578,35 @@ extern "C" int mudpt_set_class_prompts(mudpt_model* m, const float* emb, const i
         max_eot = std::max(max_eot, (int)eot[cc]);
     }
     const size_t Le = m->txt_trim ? (size_t)std::max(max_eot + 1, c.n_ctx + 2) : L;
-    m->txt.L = (int)Le;
-    m->txt.Lp = attn_padded_len((int)Le);
+    // Sequences per text-tower pass.  MuDPT: the C class prompts.  CoCoOp: every image has its own C prompts (trainers/cocoop.py:187-194
+    // loops over the images, C sequences at a time); here a CHUNK of images goes through the tower at once -- as many as fit a
+    // memory budget (activations for the backward are ~150 KB per token at width 512) and the kernels' 32-bit offsets -- and
+    // cocoop_forward / cocoop_forward_backward loop over the chunks.  The reference's own config (train batch 1, test batch 100, up to
+    // 1000 classes) therefore needs C * Le tokens of activations at least, never max_batch * C * ctx_len.
+    size_t chunk = 1;
+    if (m->cocoop) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        for (void* p : m->txt.act_allocs) (void)hipFree(p);  // a previous sizing does not count against the budget
+        m->txt.act_allocs.clear();
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t per_row = tower_bytes_per_row(m->txt), budget = (size_t)((double)free_b * 0.6);
+        size_t rows_max = budget / per_row;
+        if (rows_max > 400000) rows_max = 400000;  // u / dqkv of one pass stay below the GEMM and attention kernels' 2 GiB offset range
+        chunk = rows_max / (C * Le);
+        if (chunk > (size_t)c.max_batch) chunk = (size_t)c.max_batch;
+        if (m->cocoop_chunk > 0 && chunk > (size_t)m->cocoop_chunk) chunk = (size_t)m->cocoop_chunk;
+        if (chunk < 1) {
+            set_error("set_class_prompts: one image's %zu class prompts x %zu positions (%zu tokens, %.1f GB of text-tower activations) "
+                      "exceed the budget of %.1f GB / 400000 tokens per pass", C, Le, C * Le, (double)(C * Le * per_row) / 1e9, (double)budget / 1e9);
+            return MUDPT_ERR_ARG;
+        }
+    }
+    m->txt_chunk = (int)chunk;
+    if (int rc = alloc_tower_acts(m, m->txt, (int)Le, (int)(m->cocoop ? chunk * C : C))) return rc;
     std::vector<float> pos(L * d), ep(C * Le * d);
     HIP_TRY(hipMemcpy(pos.data(), m->tpos, pos.size() * 4, hipMemcpyDeviceToHost));
-    const size_t reps = m->cocoop ? (size_t)c.max_batch : 1;  // CoCoOp: sequence i * C + c for every image i
+    const size_t reps = chunk;  // CoCoOp: sequence i * C + c for every image i of a chunk (the tables are chunk-local, reused per chunk)
     std::vector<int> rows(C * reps), tr(C * reps * c.n_ctx);
     for (size_t cc = 0; cc < C; ++cc) {
         for (size_t i = 0; i < reps; ++i) rows[i * C + cc] = (int)((i * C + cc) * Le) + eot[cc];
@@ -617,19 +722,19 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
         if (lp) l1.add_lp = t.upd; else l1.add = t.upd;
         if (splice) { l1.ov_rows = splice; l1.ov_row0 = t.prompt_row0; l1.ov_n = n; l1.ov_L = t.L; }
     }
-    TRY(launch_ln_fwd(dt, l1, s));
+    TRY(ln_fwd_call(m, t, l1, s));
     GemmArgs q; q.A = t.h; q.lda = sp * d; q.B = t.split ? w.w_in2 : w.w_in; q.ldb = sp * d; q.M = M; q.N = 3 * d; q.K = sp * d; q.bias = w.b_in; q.out0 = a.qkv; q.ldo0 = 3 * d;
     TRY(gemm_call(m, EPI_STORE, q, s));
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
     if (t.split) { at.ld_out = 2 * d; at.out_lo = (char*)a.attn + (size_t)d * esz; }
-    TRY(launch_attn_fwd(dt, at, s));
+    TRY(attn_call(m, t, at, false, s));
     if (i + 1 == t.layers) return block_fwd_tail(m, t, nseq, s);
     GemmArgs o; o.A = a.attn; o.lda = sp * d; o.B = t.split ? w.w_out2 : w.w_out; o.ldb = sp * d; o.M = M; o.N = d; o.K = sp * d; o.bias = w.b_out; o.out0 = t.upd; o.ldo0 = d;
     TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, o, s));
     LnFwdArgs l2; l2.x = a.x_in; l2.ldx = d; if (lp) l2.add_lp = t.upd; else l2.add = t.upd; l2.ldadd = d; l2.xout = a.x_mid; l2.ldxout = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = sp * d;
     if (t.split) l2.out_lo = (char*)t.h + (size_t)d * esz;
     l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = M; l2.d = d;
-    TRY(launch_ln_fwd(dt, l2, s));
+    TRY(ln_fwd_call(m, t, l2, s));
     GemmArgs f; f.A = t.h; f.lda = sp * d; f.B = t.split ? w.w_fc2 : w.w_fc; f.ldb = sp * d; f.M = M; f.N = 4 * d; f.K = sp * d; f.bias = w.b_fc; f.out0 = a.u; f.ldo0 = 4 * d;
     f.out1 = t.g; f.ldo1 = sp * 4 * d;
     if (t.split) f.out1_lo = (char*)t.g + (size_t)4 * d * esz;
@@ -662,7 +767,7 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.dout = t.dattn; at.dqkv = t.dqkv; at.delta = t.delta; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
     if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
     at.sel_rows = t.tail_rows;       // d(attention output) is zero except on those rows: the kernels skip the all-zero query blocks
-    TRY(launch_attn_bwd(dt, at, s));
+    TRY(attn_call(m, t, at, true, s));
     GemmArgs g4; g4.A = t.dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 3 * d; g4.out0 = t.h; g4.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g4, s));
     // the residual path into ln_1's input: d(x_mid), zero except on the selected rows
@@ -675,7 +780,7 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     LnBwdArgs b1; b1.dy = t.h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.lddres = d;
     if (m->lp_grad) b1.dres_lp = t.dx_lp; else { b1.dres = t.dx; b1.dx = t.dx; }
     b1.lddx = d; b1.dx_lp = t.dx_lp; b1.lddx_lp = d; b1.rows = M; b1.d = d;
-    TRY(launch_ln_bwd(dt, b1, s));
+    TRY(ln_bwd_call(m, t, b1, s));
     return MUDPT_OK;
 }
 
@@ -691,12 +796,12 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
     LnBwdArgs b2; b2.dy = t.h; b2.lddy = d; b2.x = a.x_mid; b2.ldx = d; b2.mean = a.mean2; b2.rstd = a.rstd2; b2.gamma = w.ln2_g; b2.lddres = d;
     if (m->lp_grad) b2.dres_lp = t.dx_lp; else { b2.dres = t.dx; b2.dx = t.dx; }
     b2.lddx = d; b2.dx_lp = t.dx_lp; b2.lddx_lp = d; b2.rows = M; b2.d = d;
-    TRY(launch_ln_bwd(dt, b2, s));
+    TRY(ln_bwd_call(m, t, b2, s));
     GemmArgs g3; g3.A = t.dx_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = M; g3.N = d; g3.K = d; g3.out0 = t.dattn; g3.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g3, s));
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.dout = t.dattn; at.dqkv = t.dqkv; at.delta = t.delta; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
     if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
-    TRY(launch_attn_bwd(dt, at, s));
+    TRY(attn_call(m, t, at, true, s));
     if (i == 0 && t.head_rows && t.layers > 1) {
         // block 0: d(x_in) on the prompt rows only (Tower::head_rows); the other rows of t.dx / t.dx_lp are left stale and
         // nothing reads them (the splice reductions and ln_pre's backward touch prompt rows only)
@@ -716,7 +821,7 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
     LnBwdArgs b1; b1.dy = t.h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.lddres = d;
     if (m->lp_grad) b1.dres_lp = t.dx_lp; else { b1.dres = t.dx; b1.dx = t.dx; }
     b1.lddx = d; b1.dx_lp = t.dx_lp; b1.lddx_lp = d; b1.rows = M; b1.d = d;
-    TRY(launch_ln_bwd(dt, b1, s));
+    TRY(ln_bwd_call(m, t, b1, s));
     return MUDPT_OK;
 }
 
@@ -749,55 +854,89 @@ static int vision_forward(mudpt_model* m, const float* images, int B, hipStream_
 // ---- CoCoOp (trainers/cocoop.py) ------------------------------------------------------------------------------------
 // forward (:178-198): image features of the frozen vanilla ViT -> meta_net bias per image (:141-146) -> one text-tower pass
 // over all B * C (image, class) prompts at once (the reference loops over the images, :187-194) -> logits [B, C].
-static int cocoop_forward(mudpt_model* m, const float* images, int B, hipStream_t s) {
+// text tower over the prompts of images [i0, i0 + nb): prompts (:148-165) + positional embedding (:52), 12 causal blocks, ln_final on
+// the EOT rows, text_projection -> rows i0 * C .. of m->txt_f
+static int cocoop_text_chunk(mudpt_model* m, int i0, int nb, hipStream_t s) {
     const mudpt_config& c = m->cfg;
-    const int dt = c.t_width, e = c.embed_dim, n = c.n_ctx, C = c.n_cls, Lt = m->txt.L, hd = m->hid, TS = B * C;
+    const int dt = c.t_width, e = c.embed_dim, n = c.n_ctx, C = c.n_cls, Lt = m->txt.L, TS = nb * C;
+    const size_t r0 = (size_t)i0 * C;
+    TRY(launch_cocoop_prompts(m->txt.a[0].x_in, m->emb_pos, m->params + m->off[Q_CTX], m->mn_bias + (size_t)i0 * dt, m->tpos, nb, C, Lt, dt, n, s));
+    for (int i = 0; i < m->txt.layers; ++i) TRY(block_fwd(m, m->txt, i, TS, nullptr, s));
+    LnFwdArgs lf; lf.x = m->txt.xout_sel; lf.ldx = dt; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln + r0 * dt; lf.ldo = dt;
+    lf.out_f32 = true; lf.mean = m->fin_mean + r0; lf.rstd = m->fin_rstd + r0; lf.rows = TS; lf.d = dt;
+    TRY(launch_ln_fwd(m->dtype, lf, s));
+    TRY(launch_sgemm(false, false, TS, e, dt, 1.f, m->t_ln + r0 * dt, dt, m->tproj, e, 0.f, m->txt_f + r0 * e, e, nullptr, s));
+    return MUDPT_OK;
+}
+
+static HeadArgs cocoop_head_args(mudpt_model* m, int i0, int nb, int B) {
+    const mudpt_config& c = m->cfg;
+    const size_t C = c.n_cls, e = c.embed_dim, r0 = (size_t)i0 * C;
+    HeadArgs h; h.img = m->img_f + (size_t)i0 * e; h.txt = m->txt_f + r0 * e; h.scale = m->scale; h.logits = m->logits + r0;
+    h.img_n = m->img_n + (size_t)i0 * e; h.txt_n = m->txt_n + r0 * e; h.img_inv = m->img_inv + i0; h.txt_inv = m->txt_inv + r0;
+    h.dlogits = m->dlogits + r0; h.row_loss = m->row_loss + i0; h.dtxt = m->dtxt + r0 * e; h.loss = m->loss;
+    h.B = nb; h.B_total = B; h.C = (int)C; h.e = (int)e;
+    return h;
+}
+
+// image features of the frozen vanilla ViT, normalised (:183), and meta_net: linear1 -> ReLU -> linear2 (:103-107, fp32) -> the
+// per-image context shift m->mn_bias [B, dt]
+static int cocoop_image_side(mudpt_model* m, const float* images, int B, hipStream_t s) {
+    const mudpt_config& c = m->cfg;
+    const int dt = c.t_width, e = c.embed_dim, hd = m->hid;
     float* Pm = m->params;
     TRY(vision_forward(m, images, B, s));
-    // image_features / ||.|| (:183) feeds both meta_net and the logits
-    HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.scale = m->scale; h.logits = m->logits; h.img_n = m->img_n; h.txt_n = m->txt_n;
-    h.img_inv = m->img_inv; h.txt_inv = m->txt_inv; h.B = B; h.C = C; h.e = e;
-    // meta_net: linear1 -> ReLU -> linear2 (:103-107), fp32
     TRY(launch_l2norm(m->img_f, m->img_n, m->img_inv, B, e, s));
     TRY(launch_sgemm(false, true, B, hd, e, 1.f, m->img_n, e, Pm + m->off[Q_W1], e, 0.f, m->mn_hid, hd, Pm + m->off[Q_B1], s));
     TRY(launch_relu(m->mn_hid, (size_t)B * hd, s));
     TRY(launch_sgemm(false, true, B, dt, hd, 1.f, m->mn_hid, hd, Pm + m->off[Q_W2], hd, 0.f, m->mn_bias, dt, Pm + m->off[Q_B2], s));
-    // prompts (:148-165) + positional embedding (:52)
-    TRY(launch_cocoop_prompts(m->txt.a[0].x_in, m->emb_pos, Pm + m->off[Q_CTX], m->mn_bias, m->tpos, B, C, Lt, dt, n, s));
-    for (int i = 0; i < m->txt.layers; ++i) TRY(block_fwd(m, m->txt, i, TS, nullptr, s));
-    LnFwdArgs lf; lf.x = m->txt.xout_sel; lf.ldx = dt; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
-    lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = TS; lf.d = dt;
-    TRY(launch_ln_fwd(m->dtype, lf, s));
-    TRY(launch_sgemm(false, false, TS, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f, e, nullptr, s));
-    TRY(launch_pair_head_fwd(h, s));
     return MUDPT_OK;
 }
 
-// forward + F.cross_entropy (:196-197) + backward w.r.t. ctx and meta_net (:222-226 freeze rule: "prompt_learner" only)
+// forward (:178-198): image features -> meta_net bias per image (:141-146) -> the text tower over the (image, class) prompts, a chunk
+// of images per pass (the reference loops image by image, :187-194) -> logits [B, C].
+static int cocoop_forward(mudpt_model* m, const float* images, int B, hipStream_t s) {
+    TRY(cocoop_image_side(m, images, B, s));
+    for (int i0 = 0; i0 < B; i0 += m->txt_chunk) {
+        const int nb = B - i0 < m->txt_chunk ? B - i0 : m->txt_chunk;
+        TRY(cocoop_text_chunk(m, i0, nb, s));
+        TRY(launch_pair_head_fwd(cocoop_head_args(m, i0, nb, B), s));
+    }
+    return MUDPT_OK;
+}
+
+// forward + F.cross_entropy (:196-197) + backward w.r.t. ctx and meta_net (:222-226 freeze rule: "prompt_learner" only).  Per chunk of
+// images: text forward, logits, CE rows, text backward, ctx / bias gradients accumulated in chunk order (fixed: reproducible).
 static int cocoop_forward_backward(mudpt_model* m, const float* images, const int64_t* labels, int B, float grad_scale, float* loss, float* logits, hipStream_t s) {
     const mudpt_config& c = m->cfg;
-    const int dt = c.t_width, e = c.embed_dim, n = c.n_ctx, C = c.n_cls, Lt = m->txt.L, hd = m->hid, TS = B * C;
+    const int dt = c.t_width, e = c.embed_dim, n = c.n_ctx, C = c.n_cls, Lt = m->txt.L, hd = m->hid;
     float *Pm = m->params, *G = m->grads;
-    TRY(cocoop_forward(m, images, B, s));
-    if (logits) HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));
+    TRY(cocoop_image_side(m, images, B, s));
     HIP_TRY(hipMemsetAsync(G, 0, m->total * 4, s));
-    HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.labels = labels; h.scale = m->scale; h.logits = m->logits; h.loss = m->loss; h.dlogits = m->dlogits;
-    h.row_loss = m->row_loss; h.dtxt = m->dtxt; h.img_n = m->img_n; h.txt_n = m->txt_n; h.img_inv = m->img_inv; h.txt_inv = m->txt_inv;
     const float unscale = grad_scale / ((float)B * m->loss_scale);  // static loss scaling, as in mudpt_forward_backward
-    h.grad_scale = m->loss_scale * (float)B; h.B = B; h.C = C; h.e = e;
-    TRY(launch_pair_head_bwd(h, s));
-    HIP_TRY(hipMemcpyAsync(loss, m->loss, 4, hipMemcpyDeviceToDevice, s));
     Tower& X = m->txt;
-    TRY(launch_sgemm(false, true, TS, dt, e, 1.f, m->dtxt, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s));
-    LnBwdArgs bf; bf.dy = m->dt_ln; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.xout_sel; bf.ldx = dt; bf.mean = m->fin_mean; bf.rstd = m->fin_rstd;
-    bf.gamma = m->ln_fin_g; bf.dx = m->lp_grad ? nullptr : X.dsel; bf.lddx = dt; bf.dx_lp = X.dsel_lp; bf.lddx_lp = dt; bf.rows = TS; bf.d = dt;
-    TRY(launch_ln_bwd(m->dtype, bf, s));
-    for (int i = X.layers - 1; i >= 0; --i) {
-        if (i == X.layers - 1) TRY(block_bwd_tail(m, X, TS, s)); else TRY(block_bwd(m, X, i, TS, s));
+    for (int i0 = 0; i0 < B; i0 += m->txt_chunk) {
+        const int nb = B - i0 < m->txt_chunk ? B - i0 : m->txt_chunk, TS = nb * C;
+        const size_t r0 = (size_t)i0 * C;
+        TRY(cocoop_text_chunk(m, i0, nb, s));
+        HeadArgs h = cocoop_head_args(m, i0, nb, B);
+        h.labels = labels + i0; h.grad_scale = m->loss_scale * (float)B;
+        TRY(launch_pair_head_fwd(h, s));
+        TRY(launch_pair_head_bwd(h, s));  // CE rows, dlogits, d(text features) of this chunk; the mean over all B rows follows the loop
+        TRY(launch_sgemm(false, true, TS, dt, e, 1.f, m->dtxt + r0 * e, e, m->tproj, e, 0.f, m->dt_ln + r0 * dt, dt, nullptr, s));
+        LnBwdArgs bf; bf.dy = m->dt_ln + r0 * dt; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.xout_sel; bf.ldx = dt; bf.mean = m->fin_mean + r0; bf.rstd = m->fin_rstd + r0;
+        bf.gamma = m->ln_fin_g; bf.dx = m->lp_grad ? nullptr : X.dsel; bf.lddx = dt; bf.dx_lp = X.dsel_lp; bf.lddx_lp = dt; bf.rows = TS; bf.d = dt;
+        TRY(launch_ln_bwd(m->dtype, bf, s));
+        for (int i = X.layers - 1; i >= 0; --i) {
+            if (i == X.layers - 1) TRY(block_bwd_tail(m, X, TS, s)); else TRY(block_bwd(m, X, i, TS, s));
+        }
+        // d ctx += sum over the chunk's (image, class) prompts of the context rows' gradient; d bias[i] = the same sum over image i's prompts
+        TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, m->lp_grad ? X.dx_lp : nullptr, TS, Lt, dt, 1, n, G + m->off[Q_CTX], false, true, unscale, s));
+        TRY(launch_cocoop_dbias(m->dtype, m->lp_grad ? nullptr : X.dx, m->lp_grad ? X.dx_lp : nullptr, m->mn_dbias + (size_t)i0 * dt, nb, C, Lt, dt, n, unscale, s));
     }
-    // d ctx = sum over all (image, class) prompts of the context rows' gradient; d bias[i] = the same sum over image i's prompts
-    TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, m->lp_grad ? X.dx_lp : nullptr, TS, Lt, dt, 1, n, G + m->off[Q_CTX], false, false, unscale, s));
-    TRY(launch_cocoop_dbias(m->dtype, m->lp_grad ? nullptr : X.dx, m->lp_grad ? X.dx_lp : nullptr, m->mn_dbias, B, C, Lt, dt, n, unscale, s));
+    TRY(launch_mean(m->row_loss, B, m->loss, s));
+    HIP_TRY(hipMemcpyAsync(loss, m->loss, 4, hipMemcpyDeviceToDevice, s));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));
     // meta_net backward (fp32, tiny): linear2, ReLU, linear1; its input (the normalised image features) is a constant
     TRY(launch_sgemm(true, false, dt, hd, B, 1.f, m->mn_dbias, dt, m->mn_hid, hd, 0.f, G + m->off[Q_W2], hd, nullptr, s));
     TRY(launch_colsum(m->mn_dbias, B, dt, dt, G + m->off[Q_B2], false, s));
@@ -1011,6 +1150,7 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
     if (!strcmp(name, "gemm_variant")) { m->gemm_variant = value; return MUDPT_OK; }
     if (!strcmp(name, "lp_grad")) { m->lp_grad = value != 0 && m->dtype == MUDPT_BF16; return MUDPT_OK; }  // both stream copies are always allocated
     if (!strcmp(name, "txt_trim")) { m->txt_trim = value != 0; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
+    if (!strcmp(name, "cocoop_chunk")) { m->cocoop_chunk = value; m->prompts_set = false; return MUDPT_OK; }  // likewise
     if (!strcmp(name, "txt_split")) {  // the [W | W] copies are made while the weights are ingested: decide before the first mudpt_set_weight
         if (m->any_weight_set) { set_error("model_set: txt_split must be set before the first mudpt_set_weight"); return MUDPT_ERR_STATE; }
         m->txt.split = value != 0 && m->dtype == MUDPT_F16;
@@ -1024,23 +1164,34 @@ extern "C" int mudpt_profile_enable(mudpt_model* m, int32_t enable) {
     ARG_CHECK(m, "profile_enable: null model");
     m->prof = enable != 0;
     m->ev_used = 0;
-    m->ev_flop.clear();
+    m->ev_rec.clear();
+    m->exec_flop = 0;
     return MUDPT_OK;
 }
-// Synchronises the device; sums over the GEMM launches recorded since the last enable / read.
-extern "C" int mudpt_profile_read(mudpt_model* m, double* gemm_ms, double* gemm_flop, int64_t* launches) {
-    ARG_CHECK(m && gemm_ms && gemm_flop && launches, "profile_read: null argument");
+// Synchronises the device; sums per kernel class over the launches recorded since the last enable / read, then clears the records.
+// out arrays have MUDPT_PROF_CLASSES entries: ms, work (class 0: algorithmic FLOPs 2 M N K; classes 1-4: algorithmic HBM bytes), launches.
+extern "C" int mudpt_profile_read_classes(mudpt_model* m, double* ms, double* work, int64_t* launches, double* executed_flop) {
+    ARG_CHECK(m && ms && work && launches, "profile_read: null argument");
     HIP_TRY(hipDeviceSynchronize());
-    double ms = 0, fl = 0;
+    for (int c = 0; c < PC_COUNT; ++c) { ms[c] = 0; work[c] = 0; launches[c] = 0; }
     for (size_t i = 0; i < m->ev_used; i += 2) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, m->ev[i], m->ev[i + 1]));
-        ms += t;
-        fl += m->ev_flop[i / 2];
+        const mudpt_model::ProfRec& r = m->ev_rec[i / 2];
+        ms[r.cls] += t; work[r.cls] += r.work; launches[r.cls] += 1;
     }
-    *gemm_ms = ms; *gemm_flop = fl; *launches = (int64_t)(m->ev_used / 2);
+    if (executed_flop) *executed_flop = m->exec_flop;
     m->ev_used = 0;
-    m->ev_flop.clear();
+    m->ev_rec.clear();
+    m->exec_flop = 0;
+    return MUDPT_OK;
+}
+extern "C" int mudpt_profile_read(mudpt_model* m, double* gemm_ms, double* gemm_flop, int64_t* launches) {
+    ARG_CHECK(m && gemm_ms && gemm_flop && launches, "profile_read: null argument");
+    double ms[PC_COUNT], work[PC_COUNT];
+    int64_t n[PC_COUNT];
+    if (int rc = mudpt_profile_read_classes(m, ms, work, n, nullptr)) return rc;
+    *gemm_ms = ms[PC_GEMM]; *gemm_flop = work[PC_GEMM]; *launches = n[PC_GEMM];
     return MUDPT_OK;
 }
 

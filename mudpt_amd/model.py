@@ -212,6 +212,15 @@ class CustomCLIP(nn.Module):
         capi.check(self.lib.mudpt_profile_read(self._h, C.byref(ms), C.byref(fl), C.byref(n)), "profile_read")
         return ms.value, fl.value, n.value
 
+    PROF_CLASSES = ("gemm_pp", "ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd")
+
+    def profile_read_classes(self):
+        """({class: (ms, work, launches)}, executed MFMA FLOPs) since the last enable / read; work = algorithmic FLOPs for "gemm_pp",
+        algorithmic HBM bytes for the LayerNorm / attention classes (vision tower launches only)."""
+        ms, work, n, ex = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)(), C.c_double()
+        capi.check(self.lib.mudpt_profile_read_classes(self._h, C.byref(ms), C.byref(work), C.byref(n), C.byref(ex)), "profile_read_classes")
+        return {k: (ms[i], work[i], n[i]) for i, k in enumerate(self.PROF_CLASSES)}, ex.value
+
     def debug_read(self, name: str, batch: int) -> torch.Tensor:
         """Flat fp32 host copy of an internal activation of the last call (test hook, see include/mudpt.h)."""
         n = C.c_size_t()

@@ -21,11 +21,11 @@ GRAD_RMS = {"fp16": 2e-2, "bf16": 1.5e-1}
 GRAD_MAX = {"fp16": 8e-2, "bf16": 1.2}  # bf16 (8-bit significand): single elements of the cancelling sums are only sanity-bounded
 
 
-def build(cfg, frozen, tokens, params, dtype, max_batch):
+def build(cfg, frozen, tokens, params, dtype, max_batch, knobs=None):
     from mudpt_amd.model import CustomCLIP, ModelShape
     shape = ModelShape(cfg.image_size, cfg.patch, cfg.v_width, cfg.v_layers, cfg.v_heads, cfg.t_width, cfg.t_layers, cfg.t_heads,
                        cfg.ctx_len, cfg.embed_dim, cfg.n_ctx, 1)
-    m = CustomCLIP(shape, frozen, tokens, max_batch=max_batch, dtype=dtype, variant="cocoop")
+    m = CustomCLIP(shape, frozen, tokens, max_batch=max_batch, dtype=dtype, variant="cocoop", knobs=knobs)
     assert m.param_names == CO.TRAINABLE_ORDER  # the reference's prompt_learner.* names, flat-bucket order
     m.set_params(params)
     return m
@@ -63,9 +63,11 @@ def test_logits_loss_grads_match_reference(case, dtype):
     assert not bad, bad
 
 
-def test_larger_batch_against_oracle_and_sgd():
+@pytest.mark.parametrize("chunk", [0, 4, 1])
+def test_larger_batch_against_oracle_and_sgd(chunk):
     """B = 6 images x 11 classes = 66 text sequences of the tiny shape, smaller batch than max_batch, then two SGD steps
-    (torch.optim.SGD semantics, as Dassl's build_optimizer) tracked against the oracle."""
+    (torch.optim.SGD semantics, as Dassl's build_optimizer) tracked against the oracle.  chunk: images per text-tower pass
+    (0 = all that fit; 4 = a full and a partial pass; 1 = the reference's own image-by-image loop, trainers/cocoop.py:187-194)."""
     cfg = O.TINY
     frozen = O.make_frozen_state(cfg, 31)
     tok = O.synthetic_tokens(cfg, 11).long()
@@ -73,7 +75,7 @@ def test_larger_batch_against_oracle_and_sgd():
     g = torch.Generator().manual_seed(33)
     images, labels = torch.randn(6, 3, cfg.image_size, cfg.image_size, generator=g), torch.randint(0, 11, (6,), generator=g)
     emb, eot = frozen["token_embedding.weight"][tok], tok.argmax(-1)
-    m = build(cfg, frozen, tok, params, "fp16", max_batch=8)
+    m = build(cfg, frozen, tok, params, "fp16", max_batch=8, knobs={"cocoop_chunk": chunk})
     p, bufs = {k: v.clone() for k, v in params.items()}, {k: None for k in params}
     for step in range(2):
         loss, logits = m.forward_backward(images, labels, return_logits=True)
@@ -89,4 +91,29 @@ def test_larger_batch_against_oracle_and_sgd():
     torch.cuda.synchronize()
     for k, v in m.named_parameters():
         assert (v.detach().cpu() - p[k]).abs().max().item() <= 1e-4, k
+    m.close()
+
+
+@pytest.mark.parametrize("n_cls,max_batch", [(100, 100), (1000, 100)])
+def test_reference_config_sizes_fit_and_run(n_cls, max_batch):
+    """The reference's own CoCoOp config is train batch 1 / test batch 100 (configs/trainers/CoCoOp/vit_b16_c4_ep10_batch1_ctxv1.yaml)
+    on class sets up to ImageNet's 1000: B * C = 100 000 prompts per test batch.  The text tower's activations are sized for a chunk
+    of images, not for max_batch * C * 77 rows (1.1 TB): create succeeds, a 100-image eval batch runs in several passes, chunks of the
+    batch give the same logits bit for bit, and a batch-1 training step works on the same handle."""
+    from mudpt_amd import synth
+    from mudpt_amd.model import CustomCLIP, ModelShape
+    shape = ModelShape(depth=1)
+    m = CustomCLIP(shape, synth.random_clip_state(shape, seed=0), synth.synthetic_tokenized_prompts(n_cls), ctx_token_ids=synth.CTX_INIT_TOKENS,
+                   max_batch=max_batch, dtype="bf16", seed=1, variant="cocoop")
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(max_batch, 3, 224, 224, generator=g).cuda()
+    m.eval()
+    full = m(images)
+    assert full.shape == (max_batch, n_cls) and torch.isfinite(full).all()
+    part = torch.cat([m(images[i:i + 25]) for i in range(0, max_batch, 25)])
+    assert torch.equal(full, part)
+    m.train()
+    loss = m.forward_backward(images[:1], torch.tensor([n_cls - 1]).cuda())
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and torch.isfinite(m.flat_grads).all() and m.flat_grads.abs().sum() > 0
     m.close()
