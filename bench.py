@@ -38,16 +38,17 @@ def flops_per_step(shape, B: int, C: int) -> float:
     return float(B) * vis + float(C) * txt
 
 
-def cpu_baseline(iters: int = 24):
+def cpu_baseline(n_cls: int = 11, iters: int = 12):
     """The CPU oracle (oracle/, a restatement of the reference's arithmetic pinned by tests/golden) timed on the host
-    cores at BASELINE config 1's shape: ViT-B/16, n_ctx 4, depth 12, batch 4, 11 classes, fp32."""
+    cores at BASELINE config 1's shape: ViT-B/16, n_ctx 4, depth 12, batch 4, fp32; n_cls = 11 (the benchmark's class list) or
+    50 (Caltech-101's base split)."""
     from oracle import mudpt_oracle as O
-    from mudpt_amd.synth import bench_tokenized_prompts, CTX_INIT_TOKENS
+    from mudpt_amd.synth import bench_tokenized_prompts, synthetic_tokenized_prompts, CTX_INIT_TOKENS
     # a one-GPU box owns a 16-core share of the host; more torch threads than that only oversubscribe it
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     cfg = O.VIT_B16
     frozen = O.make_frozen_state(cfg, 0)
-    tok = bench_tokenized_prompts().long()
+    tok = (bench_tokenized_prompts() if n_cls == 11 else synthetic_tokenized_prompts(n_cls)).long()
     emb, eot = frozen["token_embedding.weight"][tok], tok.argmax(-1)
     params = O.make_trainable_state(cfg, 1, frozen, CTX_INIT_TOKENS)
     g = torch.Generator().manual_seed(1234)
@@ -61,7 +62,11 @@ def cpu_baseline(iters: int = 24):
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(4 / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} fwd+bwd iterations of BASELINE config 1 (batch 4, 11 classes, fp32), median {med * 1e3:.0f} ms"}
+            "sample": f"{iters} fwd+bwd iterations of BASELINE config 1 (batch 4, {n_cls} classes, fp32), median {med * 1e3:.0f} ms"}
+
+
+PEAK_HBM_GBS = 8000.0  # HBM3E spec (MI355X_MICROARCH.md; ~6300 GB/s achievable by a streaming copy)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_bytes_per_step.json")  # tools/prof_join.py output of the same command (PMC passes)
 
 
 def main():
@@ -78,6 +83,7 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning knob passed to mudpt_model_set (A/B runs on one box)")
     ap.add_argument("--fp32-streams", action="store_true", help="keep the update / gradient streams in fp32 (A/B of the bf16 streams)")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a captured hipGraph (implies --no-profile)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the short fp16 (parity configuration) timing appended to the bf16 line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,15 +157,50 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    gemm_ms, gemm_flop, gemm_n = model.profile_read() if not args.no_profile else (0.0, 0.0, 0)
+    classes, exec_flop = model.profile_read_classes() if not args.no_profile else ({}, 0.0)
+    gemm_ms, gemm_flop, gemm_n = classes.get("gemm_pp", (0.0, 0.0, 0))
     model.profile(False)
+    collective = None
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        # what the one collective of a step costs on its own: the 4.97 MB bucket, timed by events around dist.all_reduce (untimed extra calls)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        dist.barrier()
+        for e0, e1 in evs:
+            e0.record()
+            dist.all_reduce(model.flat_grads)
+            e1.record()
+        torch.cuda.synchronize()
+        us = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
+        collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "op": "all_reduce(sum) of the flat gradient bucket, one per step",
+                      "bucket_bytes": model.flat_grads.numel() * 4, "allreduce_us_median": round(us[len(us) // 2], 1), "allreduce_us_min": round(us[0], 1)}
     loss_v = float(loss.item())
     if not (loss_v == loss_v) or abs(loss_v) == float("inf"):
         raise SystemExit(f"non-finite loss {loss_v}")
+    model.close()
+    del model
+
+    # the parity configuration (fp16 operands, fp32 residual / update / gradient streams, split text-tower operands: logits within 1e-3 of
+    # the reference) timed on the same box right after the bf16 headline, so the driver's record carries both
+    parity_ms = None
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_parity_mode and not args.graph:
+        pm = CustomCLIP(shape, synth.random_clip_state(shape, seed=0), tok, ctx_token_ids=synth.CTX_INIT_TOKENS, max_batch=B, dtype="fp16",
+                        device=f"cuda:{local}", seed=1)
+        for _ in range(3):
+            pm.forward_backward(images, labels)
+            pm.sgd_step(lr, momentum=0.9, weight_decay=5e-4)
+        torch.cuda.synchronize()
+        n_par = max(5, args.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(n_par):
+            pm.forward_backward(images, labels)
+            pm.sgd_step(lr, momentum=0.9, weight_decay=5e-4)
+        torch.cuda.synchronize()
+        parity_ms = (time.perf_counter() - t1) / n_par * 1e3
+        pm.close()
+        del pm
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -173,30 +214,50 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss_v, 4),
                        "step_tflop": round(step_flop / 1e12, 3)},
         }
+        traffic_db = json.load(open(TRAFFIC_JSON)).get("classes", {}) if os.path.exists(TRAFFIC_JSON) and B == 256 and C == 11 and args.dtype == "bf16" and args.arch == "vit_b16" else {}
         if gemm_n:
             ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
-            # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this same command
-            # (PMC counters cannot be read from inside the process); the summary is committed under profiles/.
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_v5.json")
-            if os.path.exists(pmc) and B == 256 and C == 11 and args.dtype == "bf16":
-                traffic = round(json.load(open(pmc))["traffic_bytes_per_launch"])
+            # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (PMC counters cannot be read from
+            # inside the process); the joined summary is committed under profiles/ (tools/prof_join.py).
+            pmc = traffic_db.get("gemm_pp")
+            hbm = {}
+            for cls in ("ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd"):
+                c_ms, c_bytes, c_n = classes.get(cls, (0.0, 0.0, 0))
+                if not c_n:
+                    continue
+                gbs = c_bytes / (c_ms * 1e-3) / 1e9
+                hbm[cls] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                            "algorithmic_bytes_per_launch": round(c_bytes / c_n), "launches_per_step": c_n // args.steps, "avg_launch_us": round(c_ms * 1e3 / c_n, 2),
+                            "ms_per_step": round(c_ms / args.steps, 3),
+                            "traffic": round(traffic_db[cls]["traffic_bytes_per_launch"]) if cls in traffic_db else None}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic_v5.md)",
+                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": round(pmc["traffic_bytes_per_launch"]) if pmc else None,
+                               "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE of separate --pmc passes, profiles/r02_bytes_per_step.md)",
                                "flop_per_launch": round(gemm_flop / gemm_n),
                                "kernel": f"gemm_pp_kernel (persistent MFMA GEMM: the {gemm_n // args.steps} big vision-tower GEMM launches per step; "
                                          "achieved = executed 2MNK / event time of those launches)",
                                "executed_gemm_tflop_per_step": round(gemm_flop / args.steps / 1e12, 3),
                                "launches_per_step": gemm_n // args.steps, "avg_launch_us": round(gemm_ms * 1e3 / gemm_n, 2),
                                "gemm_share_of_step": round(gemm_ms / (elapsed * 1e3), 4),
-                               # whole step, in the reference's algorithmic FLOPs (73.5 GFLOP per image); the library skips
-                               # the rows of the last block's tail / block 0's backward that nothing uses, so this
-                               # credits that elimination; executed_gemm_tflop_per_step is what actually ran on the matrix cores
-                               "step_achieved": round(step_flop / (ms * 1e-3) / 1e12, 1), "step_frac": round(step_flop / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4)}
+                               # whole step.  step_* use the reference's ALGORITHMIC FLOPs (73.5 GFLOP per image): the library skips
+                               # rows nothing uses (the last block's tail, block 0's backward, text positions behind the last EOT), so
+                               # that figure credits eliminated work and is NOT a utilisation.  executed_* counts what ran on the matrix cores
+                               # (every GEMM and attention launch of both towers): executed_frac is the step's MFMA utilisation against the 2.5 PF peak.
+                               "step_achieved": round(step_flop / (ms * 1e-3) / 1e12, 1), "step_frac": round(step_flop / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                               "executed_tflop_per_step": round(exec_flop / args.steps / 1e12, 3),
+                               "executed_frac": round(exec_flop / args.steps / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                               # the HBM-bound kernels of the step (LayerNorm with the fused residual add / splice; attention, dQ + dK/dV kernels
+                               # together): algorithmic bytes / HIP-event time of the vision tower's launches, against the 8 TB/s spec
+                               "hbm_kernels": hbm}
+        if parity_ms is not None:
+            out["parity_mode_ms_per_step"] = round(parity_ms, 3)
+            out["parity_mode"] = "dtype fp16: fp16 MFMA operands, fp32 residual / update / gradient streams, split text-tower operands (logits within 1e-3 of the reference: tests/test_model_gpu.py)"
+        if collective is not None:
+            out["collective"] = collective
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(11, 12)
+            out["cpu_baseline_c50"] = cpu_baseline(50, 6)
         print(json.dumps(out), flush=True)
-    model.close()
     if dist is not None:
         dist.destroy_process_group()
 

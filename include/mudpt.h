@@ -126,7 +126,8 @@ int mudpt_sgd_reset(mudpt_model* m);
 int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* host_out, size_t capacity, size_t* numel);
 
 /* Per-handle tuning knobs for A/B measurements in one process (tools/gemm_bench.py, tests); nothing is process-global, so two
- * models in one process do not interfere: "gemm_variant"; "lp_grad" (bf16 mode: 0 keeps the gradient / update streams in fp32);
+ * models in one process do not interfere: "gemm_variant"; "attn_two_kernels" (1 = attention backward as two kernels); "cocoop_chunk"
+ * (cap on the images per CoCoOp text-tower pass; read by the next mudpt_set_class_prompts); "lp_grad" (bf16 mode: 0 keeps the gradient / update streams in fp32);
  * "txt_split" (fp16 mode: 0 = no split operands in the text tower; only before the first mudpt_set_weight); "txt_trim"
  * (0 = run the text tower on all ctx_len positions; read by the next mudpt_set_class_prompts, which must follow). */
 int mudpt_model_set(mudpt_model* m, const char* name, int32_t value);
@@ -160,6 +161,9 @@ int mudpt_layernorm_bwd(int32_t dtype, const void* dy, int32_t lddy, int32_t dy_
 int mudpt_attention_padded_len(int32_t L);
 int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H,
                         int32_t causal, void* stream);
+/* causal: bit 0 = causal mask.  Kernel choice (tests / A-B; default: the fused single pass over Q, K, V, dO -- delta stays on chip --
+ * for padded lengths <= 96, the dQ kernel + dK/dV kernel pair above that): bit 1 = force the two kernels, bit 3 = force the fused pass,
+ * bit 2 = force the fused pass with two 16-row blocks per wave. */
 int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                         float* delta, void* dqkv, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream);
 /* LayerNorm forward with everything the transformer block fuses into it (clip/model.py:281-301): v = x[r] + add[r] (fp32 add or T

@@ -506,6 +506,215 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward, fused: dQ, dK, dV of a (sequence, head) pair from ONE resident pass over Q, K, V, dO
+// ------------------------------------------------------------------------------------------------
+// The two-kernel form above reads Q, K, V and dO from HBM twice (948 MB per layer at B 256 / L 201 / H 12 where one pass needs
+// 632 MB) and round-trips delta through HBM.  Here one persistent workgroup per CU keeps all four [Lp][64] images of a pair in LDS
+// (4 x 28 KB at Lp = 224) and runs both sweeps on them -- still two independent sweeps (no dS image, no atomics, bitwise
+// reproducible), recomputing S and dP once as before:
+//   phase A (query on the lane, = attn_bwd_dq_kernel's block): dQ from the K / V images and this wave's Q / dO / O fragments; delta and
+//     -lse log2(e) go to LDS for phase B.  Meanwhile the pair's Q / dO images arrive by LDS-DMA.
+//   phase B (key on the lane, = attn_bwd_dkv_kernel's block): dK, dV from the Q / dO images; the wave's K / V fragments were read from
+//     the K / V images at the end of phase A, so those images are free: the NEXT pair's K / V stream into them, and the next pair's
+//     Q / dO / O fragments travel to registers.
+// One barrier between the phases and one per pair; the only exposed memory latency is the first pair's.  The fragments of the
+// "own" operand (Q / dO in phase A) are fetched straight from global memory half a pair before the same lines are DMA-ed as images:
+// that second touch is served by the L2 / Infinity Cache, not by HBM.
+// Image rows >= L hold the next sequence's rows (finite values; zeros past the end of the tensor through the buffer descriptor):
+// padded keys are masked by the -inf initial value of their score accumulators, padded queries by lse = -inf, so P = 0 meets them.
+// W2 = waves per 32 rows: 1 -> NC waves, two 16-row blocks per wave and phase; 2 -> 2 NC waves, one block each.
+// Measured (round 2, tools/attn_bench.py, bf16): text tower, 1000 x 8 pairs of L = 77: 212 us vs 260 us for the two kernels; 11 x 8 pairs
+// 7.5 vs 12.9 us -- several workgroups fit a CU (NC <= 3: <= 51 KB of LDS).  Vision tower (B 256, L 201, H 12: NC = 7, 117 KB, ONE
+// workgroup per CU): 297 us (W2 = 2, 24 spilled VGPRs at the 128-register cap of 14 waves) / 275 us (W2 = 1) vs 261 us for the two
+// kernels at two workgroups per CU: the kernels are bound by instruction issue (VALU ~ MFMA ~ LDS issue, ~20 us per pair per CU against
+// 4.4 us of matrix-pipe time), not by the 948 -> 632 MB of HBM traffic the single pass saves, and one workgroup per CU hides less
+// latency.  So the dispatcher uses this kernel for NC <= 3 and the two-kernel form above it.
+template <typename T, int NC, bool CAUSAL, int W2>
+__global__ __launch_bounds__(NC * 64 * W2) void attn_bwd_fused_kernel(AttnArgs p, const void* fwd_out, int npairs) {
+    using A = Attn<T>;
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    constexpr int Lp = NC * 32, NW = NC * W2, NT = NW * 64, IMG = Lp * 128, NBLK = 2 / W2, RGW = 8 / W2;  // RGW: 8-row groups per wave per image pair
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const elem* Ks = (const elem*)smem;
+    const elem* Vs = (const elem*)(smem + IMG);
+    const elem* Qs = (const elem*)(smem + 2 * IMG);
+    const elem* Gs = (const elem*)(smem + 3 * IMG);
+    float* kmask = (float*)(smem + 4 * IMG);  // [Lp] 0 for real keys, -inf for padding
+    float* lse_s = kmask + Lp;                // [Lp] -lse log2(e) of the current pair's queries (-inf for padding)
+    float* del_s = lse_s + Lp;                // [Lp] delta = rowsum(dO * O)
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HD = p.H * 64, L = p.L;
+    const size_t ld = (size_t)3 * HD;
+    const size_t ldof = p.ld_out ? (size_t)p.ld_out : (size_t)HD;  // the forward output may be the hi half of a [hi | lo] row
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.qkv), 0, (int)((size_t)p.B * L * ld * 2), 0x00020000);
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dout), 0, (int)((size_t)p.B * L * HD * 2), 0x00020000);
+    // lane part of a DMA source: row (lane >> 3) of an 8-row group, 16-byte chunk (lane & 7) ^ (row & 7) (the LDS slot is lane-linear)
+    const unsigned lane_q = (unsigned)(((size_t)(lane >> 3) * ld + (size_t)(((lane & 7) ^ (lane >> 3)) << 3)) * 2);
+    const unsigned lane_g = (unsigned)(((size_t)(lane >> 3) * HD + (size_t)(((lane & 7) ^ (lane >> 3)) << 3)) * 2);
+    using lds_ptr = __attribute__((address_space(3))) void*;
+    // K and V images of a pair -> smem[0, 2 IMG)
+    auto issue_kv = [&](int pair) {
+        const int b = pair / p.H, hd = pair - b * p.H;
+        const unsigned base = (unsigned)(((size_t)b * L * ld + (size_t)hd * 64) * 2);
+#pragma unroll
+        for (int k = 0; k < RGW; ++k) {
+            const int j = wave * RGW + k, img = j / (Lp / 8), rg = j - img * (Lp / 8);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr)(smem + img * IMG + rg * 1024), 16,
+                                                     (int)(base + (unsigned)((1 + img) * HD * 2) + lane_q + (unsigned)(rg * 8) * (unsigned)(ld * 2)), 0, 0, 0);
+        }
+    };
+    // Q and dO images of a pair -> smem[2 IMG, 4 IMG)
+    auto issue_qg = [&](int pair) {
+        const int b = pair / p.H, hd = pair - b * p.H;
+        const unsigned baseq = (unsigned)(((size_t)b * L * ld + (size_t)hd * 64) * 2), baseg = (unsigned)(((size_t)b * L * HD + (size_t)hd * 64) * 2);
+#pragma unroll
+        for (int k = 0; k < RGW; ++k) {
+            const int j = wave * RGW + k, img = j / (Lp / 8), rg = j - img * (Lp / 8);
+            if (img == 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr)(smem + 2 * IMG + rg * 1024), 16, (int)(baseq + lane_q + (unsigned)(rg * 8) * (unsigned)(ld * 2)), 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr)(smem + 3 * IMG + rg * 1024), 16, (int)(baseg + lane_g + (unsigned)(rg * 8) * (unsigned)(HD * 2)), 0, 0, 0);
+        }
+    };
+    struct QFrags { vec8 q0, q1, g0, g1, o0, o1; float lse; };
+    auto fetch_q = [&](int pair, int qb) {
+        const int b = pair / p.H, hd = pair - b * p.H, q = qb * 16 + c;
+        const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
+        const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
+        const elem* Of = (const elem*)fwd_out + (size_t)b * L * ldof + hd * 64;
+        QFrags f{A::grow(base, ld, q, L, 0, lane), A::grow(base, ld, q, L, 1, lane), A::grow(dO, HD, q, L, 0, lane), A::grow(dO, HD, q, L, 1, lane),
+                 A::grow(Of, ldof, q, L, 0, lane), A::grow(Of, ldof, q, L, 1, lane), 0.f};
+        f.lse = q < Lp ? p.lse[(size_t)pair * Lp + q] : 0.f;
+        return f;
+    };
+    struct KFrags { vec8 k0, k1, v0, v1; };
+
+    const int nb16 = (L + 15) >> 4;  // 16-row blocks that hold a real row (queries and keys alike)
+    // ---- phase A block: dQ of query block qb; leaves delta / lse of its queries in LDS ------------------------------------
+    auto phase_a = [&](int pair, int qb, const QFrags& f) {
+        const int b = pair / p.H, hd = pair - b * p.H, q = qb * 16 + c;
+        float delta = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) delta += (float)f.g0[i] * (float)f.o0[i] + (float)f.g1[i] * (float)f.o1[i];
+        delta = group_sum(delta);
+        const float nlse = -f.lse * LOG2E;
+        if (g == 0) {
+            del_s[q] = delta;
+            lse_s[q] = q < L ? nlse : -INFINITY;
+        }
+        const int nkc = CAUSAL ? (qb >> 1) + 1 : NC;
+        f32x4 dQ[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kc = 0; kc < nkc; ++kc) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = 2 * kc + t;
+                f32x4 S = *(const f32x4*)(kmask + kt * 16 + 4 * g), dP = {-delta, -delta, -delta, -delta};
+                S = T::mfma16(A::rows(Ks, kt * 16, 0, lane), f.q0, S);
+                S = T::mfma16(A::rows(Ks, kt * 16, 1, lane), f.q1, S);
+                dP = T::mfma16(A::rows(Vs, kt * 16, 0, lane), f.g0, dP);
+                dP = T::mfma16(A::rows(Vs, kt * 16, 1, lane), f.g1, dP);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nlse));
+                    if (CAUSAL && kt * 16 + 4 * g + r > q) pr = 0.f;
+                    ds[t][r] = pr * dP[r];
+                }
+            }
+            const vec8 db = A::pack2(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dQ[dt] = T::mfma16(A::cols(Ks, kc * 32, dt * 16, lane), db, dQ[dt]);
+        }
+        if (q < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + q) * ld + hd * 64, dQ, 0.125f, lane);
+    };
+    // ---- phase B block: dK, dV of key block kb --------------------------------------------------------------------------------
+    auto phase_b = [&](int pair, int kb, const KFrags& f) {
+        const int b = pair / p.H, hd = pair - b * p.H, key = kb * 16 + c;
+        f32x4 dK[4], dV[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const int qc0 = CAUSAL ? (kb >> 1) : 0;
+#pragma unroll 1
+        for (int qc = qc0; qc < NC; ++qc) {
+            f32x4 P[2], dS[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qt = 2 * qc + t;
+                const f32x4 nl = *(const f32x4*)(lse_s + qt * 16 + 4 * g);
+                const f32x4 d4 = *(const f32x4*)(del_s + qt * 16 + 4 * g);
+                f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = -d4;
+                S = T::mfma16(A::rows(Qs, qt * 16, 0, lane), f.k0, S);
+                S = T::mfma16(A::rows(Qs, qt * 16, 1, lane), f.k1, S);
+                dP = T::mfma16(A::rows(Gs, qt * 16, 0, lane), f.v0, dP);
+                dP = T::mfma16(A::rows(Gs, qt * 16, 1, lane), f.v1, dP);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nl[r]));
+                    if (CAUSAL && key > qt * 16 + 4 * g + r) pr = 0.f;
+                    P[t][r] = pr;
+                    dS[t][r] = pr * dP[r];
+                }
+            }
+            const vec8 pb = A::pack2(P[0], P[1]), db = A::pack2(dS[0], dS[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dV[dt] = T::mfma16(A::cols(Gs, qc * 32, dt * 16, lane), pb, dV[dt]);
+                dK[dt] = T::mfma16(A::cols(Qs, qc * 32, dt * 16, lane), db, dK[dt]);
+            }
+        }
+        if (key < L) {
+            elem* ok = (elem*)p.dqkv + ((size_t)b * L + key) * ld + HD + hd * 64;
+            A::store_t(ok, dK, 0.125f, lane);
+            A::store_t(ok + HD, dV, 1.f, lane);
+        }
+    };
+
+    for (int i = tid; i < Lp; i += NT) { kmask[i] = i < L ? 0.f : -INFINITY; lse_s[i] = -INFINITY; del_s[i] = 0.f; }
+    int pair = blockIdx.x;
+    QFrags qf[NBLK];
+    if (pair < npairs) {
+        issue_kv(pair);
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) qf[j] = fetch_q(pair, wave + j * NW);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (; pair < npairs; pair += gridDim.x) {
+        // ---- phase A ----
+        issue_qg(pair);
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j)
+            if (wave + j * NW < nb16) phase_a(pair, wave + j * NW, qf[j]);
+        KFrags kf[NBLK];
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
+            const int r0 = (wave + j * NW) * 16;  // < Lp: 2 NC blocks in all
+            kf[j] = KFrags{A::rows(Ks, r0, 0, lane), A::rows(Ks, r0, 1, lane), A::rows(Vs, r0, 0, lane), A::rows(Vs, r0, 1, lane)};
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // Q / dO images landed, this wave's K / V fragments and dQ stores are done
+        __syncthreads();                                              // ... for every wave: the K / V images are free, lse_s / del_s are complete
+        // ---- phase B ----
+        const int nxt = pair + gridDim.x;
+        if (nxt < npairs) {
+            issue_kv(nxt);
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j) qf[j] = fetch_q(nxt, wave + j * NW);
+        }
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j)
+            if (wave + j * NW < nb16) phase_b(pair, wave + j * NW, kf[j]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next pair's K / V images and fragments have landed
+        __syncthreads();                                  // ... for every wave, and everyone is done with the Q / dO images and lse_s / del_s
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Long sequences (L > 224: ViT-L/14@336 has 577 + n_ctx vision tokens, BASELINE configs[4]): the other operand no longer
 // fits in LDS as a whole, so it streams through a 64-row stage and the forward keeps a running (online) softmax.  Same
 // fragment conventions and inner products as the whole-sequence kernels above; one workgroup = 4 waves = 64 rows of the
@@ -830,12 +1039,37 @@ static int bwd_cfg(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
     return MUDPT_OK;
 }
 
+// fused backward (one resident pass): everything except the sel_rows form of the last block
+template <typename T, int NC, bool CAUSAL, int W2>
+static int bwd_fused_cfg(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
+    constexpr int lds = 4 * NC * 32 * 128 + 3 * NC * 32 * 4;
+    auto kern = attn_bwd_fused_kernel<T, NC, CAUSAL, W2>;
+    static PerDevice pd;
+    const int dev = current_device();
+    if (!pd.done[dev]) {
+        if (int e = set_lds(kern, lds)) return e;
+        HIP_TRY(hipDeviceGetAttribute(&pd.ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+        pd.done[dev] = true;
+    }
+    const int npairs = a.B * a.H, by_lds = 163840 / lds, by_waves = 32 / (NC * W2);
+    int per_cu = by_lds < by_waves ? by_lds : by_waves;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int cap = pd.ncu[dev] * per_cu;
+    MUDPT_LAUNCH(kern, dim3(npairs < cap ? npairs : cap), dim3(NC * 64 * W2), lds, s, prof, a, (const void*)a.out, npairs);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
 template <typename T, bool BWD>
 static int dispatch(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
     if (a.L > 224) return tiled_launch<T, BWD>(a, s, prof);  // the other operand streams through 64-row stages
     const int nc = attn_padded_len(a.L) / 32;
 #define MUDPT_ATTN_CASE(N)                                                                     \
     case N:                                                                                    \
+        if (BWD && !a.sel_rows && !a.two_kernels && (N <= 3 || a.force_fused)) {                   \
+            if (a.fused_w1) return a.causal ? bwd_fused_cfg<T, N, true, 1>(a, s, prof) : bwd_fused_cfg<T, N, false, 1>(a, s, prof); \
+            return a.causal ? bwd_fused_cfg<T, N, true, 2>(a, s, prof) : bwd_fused_cfg<T, N, false, 2>(a, s, prof); \
+        }                                                                                          \
         if (a.causal) return BWD ? bwd_cfg<T, N, true>(a, s, prof) : fwd_cfg<T, N, true>(a, s, prof);      \
         return BWD ? bwd_cfg<T, N, false>(a, s, prof) : fwd_cfg<T, N, false>(a, s, prof);
     switch (nc) {

@@ -36,7 +36,11 @@ __device__ inline void vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int EPI>
+// ST / LD: cache policy of the epilogue's output stores / of EPI_GELU_BWD's one-touch aux read (aux bits of the buffer instructions on
+// gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Measured in round 2 (tools/gemm_bench.py, A/B in one process, B = 256 shapes): write-through
+// sc1 / sc0 sc1 stores are 8-60 % SLOWER (fc 315 -> 515 us: the L2 no longer absorbs the store bursts), nt stores and nt aux loads
+// are within +-1 % over the 8 GEMMs of a block.  Plain policy everywhere; the parameters stay for the next experiment.
+template <typename T, int EPI, int ST = 0, int LD = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int ntiles, int rem_half) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
@@ -246,8 +250,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int off = i < ni ? row_off(i, p.ldaux, 2, n) : OOB;
-                    u[i][0] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off, 0, 0));
-                    u[i][1] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off, 16, 0));
+                    u[i][0] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off, 0, LD));
+                    u[i][1] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off, 16, LD));
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
@@ -266,14 +270,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                     // natural layout: the 4 lanes of a row write 64 contiguous bytes per instruction (permuted: 16-byte pieces
                     // 64 bytes apart, measured 1.55x slower)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsOut0, row_off(i, p.ldo0, 4, n + 16 * j), 0, 0);
+                    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsOut0, row_off(i, p.ldo0, 4, n + 16 * j), 0, ST);
                 } else {
                     vec8 o0, o1;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { o0[c] = (elem)acc[i][0][c]; o0[4 + c] = (elem)acc[i][1][c]; o1[c] = (elem)acc[i][2][c]; o1[4 + c] = (elem)acc[i][3][c]; }
                     const int off = row_off(i, p.ldo0, 2, n);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut0, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut0, off, 16, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut0, off, 0, ST);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut0, off, 16, ST);
                     if constexpr (EPI == EPI_GELU) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
@@ -281,8 +285,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                             o1[c] = (elem)quick_gelu(acc[i][2][c]); o1[4 + c] = (elem)quick_gelu(acc[i][3][c]);
                         }
                         const int off1 = row_off(i, p.ldo1, 2, n);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut1, off1, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut1, off1, 16, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut1, off1, 0, ST);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut1, off1, 16, ST);
                     }
                 }
                 }
@@ -374,10 +378,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the second group's extra barrier
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int ST = 0, int LD = 0>
 static int launch_pp(const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
     constexpr int lds = 2 * 65536;
-    auto kern = gemm_pp_kernel<T, EPI>;
+    auto kern = gemm_pp_kernel<T, EPI, ST, LD>;
     static PerDevice pd;
     const int dev = current_device();
     if (!pd.done[dev]) {
@@ -420,7 +424,7 @@ int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s, const G
     ARG_CHECK((size_t)a.M * a.lda * 2 < 0xffffffffull && (size_t)a.N * a.ldb * 2 < 0xffffffffull, "gemm_pp: operand larger than 4 GiB");
     ARG_CHECK(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldo0 % 8 == 0, "gemm_pp: strides must be multiples of 8");
     // epilogue offsets are 32-bit and rely on the descriptors' range check for rows >= M
-    ARG_CHECK((size_t)a.M * a.ldo0 * 4 < 0x7fffffffull && (size_t)a.M * (size_t)(a.ldo1 > a.ldaux ? a.ldo1 : a.ldaux) * 2 < 0x7fffffffull, "gemm_pp: output larger than 2 GiB");
+    ARG_CHECK((size_t)a.M * a.ldo0 * (epi == EPI_STORE_F32 ? 4 : 2) < 0x7fffffffull && (size_t)a.M * (size_t)(a.ldo1 > a.ldaux ? a.ldo1 : a.ldaux) * 2 < 0x7fffffffull, "gemm_pp: output larger than 2 GiB");
     if (dtype == DT_BF16) return launch_pp_t<BF16>(epi, a, s, o);
     if (dtype == DT_F16) return launch_pp_t<F16>(epi, a, s, o);
     set_error("gemm: unknown dtype %d", dtype);

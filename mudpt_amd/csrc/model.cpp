@@ -152,6 +152,8 @@ struct mudpt_model {
     // per-handle tuning knobs (mudpt_model_set): nothing here is process-global, two models in one process do not interfere
     int gemm_variant = 0;
     bool txt_trim = true;  // run the text tower on positions 0..max(eot) only (read by mudpt_set_class_prompts)
+    bool attn_fused_w1 = false;
+    bool attn_two_kernels = false;  // knob: attention backward as the dQ + dK/dV kernel pair instead of the fused single pass
     int cocoop_chunk = 0;  // knob: cap on the images per text-tower pass (0 = as many as the memory budget allows)
     int txt_chunk = 1;     // CoCoOp: images per text-tower pass, set by mudpt_set_class_prompts
     bool any_weight_set = false;
@@ -220,7 +222,10 @@ static int ln_bwd_call(mudpt_model* m, const Tower& t, const LnBwdArgs& a, hipSt
     if (int rc = prof_next(m, PC_LN_BWD, per_elem * a.rows * a.d, &lp)) return rc;
     return launch_ln_bwd(m->dtype, a, s, &lp);
 }
-static int attn_call(mudpt_model* m, const Tower& t, const AttnArgs& a, bool bwd, hipStream_t s) {
+static int attn_call(mudpt_model* m, const Tower& t, const AttnArgs& a0, bool bwd, hipStream_t s) {
+    AttnArgs a = a0;
+    a.two_kernels = m->attn_two_kernels;
+    a.fused_w1 = m->attn_fused_w1;
     // executed MFMA FLOPs: forward S = QK^T and PV (2 products of 2 L^2 64 each per head); backward 7 products (dQ sweep: S, dP, dQ;
     // dK/dV sweep: S, dP, dV, dK); the causal tower does about half of each
     const double prod = 2.0 * a.L * (double)a.L * 64.0 * a.H * a.B * (a.causal ? 0.5 : 1.0);
@@ -592,13 +597,15 @@ extern "C" int mudpt_set_class_prompts(mudpt_model* m, const float* emb, const i
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const size_t per_row = tower_bytes_per_row(m->txt), budget = (size_t)((double)free_b * 0.6);
         size_t rows_max = budget / per_row;
-        if (rows_max > 400000) rows_max = 400000;  // u / dqkv of one pass stay below the GEMM and attention kernels' 2 GiB offset range
+        // the widest row of a pass (QuickGELU(u) as a split [hi | lo] operand: 8 d elements) stays inside the kernels' 32-bit byte offsets
+        const size_t rows_cap = (size_t)0x7fffffff / ((size_t)16 * d) - 1;
+        if (rows_max > rows_cap) rows_max = rows_cap;
         chunk = rows_max / (C * Le);
         if (chunk > (size_t)c.max_batch) chunk = (size_t)c.max_batch;
         if (m->cocoop_chunk > 0 && chunk > (size_t)m->cocoop_chunk) chunk = (size_t)m->cocoop_chunk;
         if (chunk < 1) {
             set_error("set_class_prompts: one image's %zu class prompts x %zu positions (%zu tokens, %.1f GB of text-tower activations) "
-                      "exceed the budget of %.1f GB / 400000 tokens per pass", C, Le, C * Le, (double)(C * Le * per_row) / 1e9, (double)budget / 1e9);
+                      "exceed the budget of %.1f GB / %zu tokens per pass", C, Le, C * Le, (double)(C * Le * per_row) / 1e9, (double)budget / 1e9, rows_cap);
             return MUDPT_ERR_ARG;
         }
     }
@@ -1150,6 +1157,8 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
     if (!strcmp(name, "gemm_variant")) { m->gemm_variant = value; return MUDPT_OK; }
     if (!strcmp(name, "lp_grad")) { m->lp_grad = value != 0 && m->dtype == MUDPT_BF16; return MUDPT_OK; }  // both stream copies are always allocated
     if (!strcmp(name, "txt_trim")) { m->txt_trim = value != 0; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
+    if (!strcmp(name, "attn_two_kernels")) { m->attn_two_kernels = value != 0; return MUDPT_OK; }
+    if (!strcmp(name, "attn_fused_w1")) { m->attn_fused_w1 = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "cocoop_chunk")) { m->cocoop_chunk = value; m->prompts_set = false; return MUDPT_OK; }  // likewise
     if (!strcmp(name, "txt_split")) {  // the [W | W] copies are made while the weights are ingested: decide before the first mudpt_set_weight
         if (m->any_weight_set) { set_error("model_set: txt_split must be set before the first mudpt_set_weight"); return MUDPT_ERR_STATE; }
@@ -1287,6 +1296,7 @@ extern "C" int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, fl
 }
 extern "C" int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int32_t B,
                                    int32_t L, int32_t H, int32_t causal, void* stream) {
-    AttnArgs a; a.qkv = qkv; a.out = (void*)out; a.dout = dout; a.lse = (float*)lse; a.delta = delta; a.dqkv = dqkv; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;
+    AttnArgs a; a.qkv = qkv; a.out = (void*)out; a.dout = dout; a.lse = (float*)lse; a.delta = delta; a.dqkv = dqkv; a.B = B; a.L = L; a.H = H;
+    a.causal = (causal & 1) != 0; a.two_kernels = (causal & 2) != 0; a.fused_w1 = (causal & 4) != 0; a.force_fused = (causal & 12) != 0;
     return launch_attn_bwd(dtype, a, (hipStream_t)stream);
 }

@@ -329,7 +329,10 @@ def test_layernorm_gather_scatter(lib):
 
 ATTN_CASES = [(3, 201, 12, False), (11, 77, 8, True), (2, 7, 3, False), (2, 33, 2, True), (1, 224, 1, False), (2, 64, 2, True),
               # L > 224: the tiled (online-softmax) kernels; 581 = ViT-L/14@336's 577 tokens + 4 prompt rows (BASELINE configs[4])
-              (2, 300, 2, False), (1, 581, 3, False), (2, 260, 2, True), (1, 225, 1, False)]
+              (2, 300, 2, False), (1, 581, 3, False), (2, 260, 2, True), (1, 225, 1, False),
+              # more (sequence, head) pairs than resident workgroups: the persistent loops of the forward and the fused backward walk
+              # several pairs per workgroup (images of the next pair stream in while the current one is computed)
+              (150, 201, 2, False), (700, 20, 8, True)]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
@@ -363,6 +366,19 @@ def test_attention_fwd_bwd(lib, dtype, B, L, H, causal):
     torch.cuda.synchronize()
     scale = dref.abs().max().item()
     torch.testing.assert_close(dqkv.cpu().float(), dref, atol=12 * EPS[dtype] * scale, rtol=8 * EPS[dtype])
+    # Every form (fixed summation order, no atomics) is bit for bit the same run to run.  The two-kernel form (bit 1), the fused single
+    # pass (bit 3: Q, K, V, dO resident once) and the fused pass with two blocks per wave (bit 2) do the same per-block arithmetic in the
+    # same order, compiled separately (fma contraction may differ): the same gradients to T-precision rounding.
+    again = torch.zeros_like(dqkv)
+    ok(lib, lib.mudpt_attention_bwd(dt, P(qc), P(out), P(doc), P(lse), P(delta), P(again), B, L, H, int(causal), None))
+    torch.cuda.synchronize()
+    assert torch.equal(again, dqkv)
+    for form in (2, 4, 8):
+        other = torch.zeros_like(dqkv)
+        ok(lib, lib.mudpt_attention_bwd(dt, P(qc), P(out), P(doc), P(lse), P(delta), P(other), B, L, H, int(causal) | form, None))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(other.cpu().float(), dref, atol=12 * EPS[dtype] * scale, rtol=8 * EPS[dtype])
+        torch.testing.assert_close(other.float(), dqkv.float(), atol=2 * EPS[dtype] * scale, rtol=2 * EPS[dtype])
 
 
 def test_attention_softmax_extremes(lib):

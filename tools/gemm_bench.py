@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--epi", type=int, default=-1, help="only the shapes with this epilogue")
     ap.add_argument("--set", default="vision", choices=["vision", "text"])
+    ap.add_argument("--library-ref", action="store_true", help="also time torch.nn.functional.linear (rocBLAS / hipBLASLt) on the same operands: a "
+                    "known-good reference for what this GPU does on the shape (diagnostic only; the product never calls it)")
     a = ap.parse_args()
     shapes = SHAPES if a.set == "vision" else TEXT_SHAPES
     lib = capi.load()
@@ -71,6 +73,20 @@ def main():
                 torch.cuda.synchronize()
                 best[v] = min(best[v], e0.elapsed_time(e1) / a.iters)
         fl = 2.0 * M * N * K
+        if a.library_ref:
+            lin_b = bias.to(tt)
+            tbest = 1e9
+            for r in range(a.rounds):
+                torch.nn.functional.linear(A, B, lin_b)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    torch.nn.functional.linear(A, B, lin_b)
+                e1.record()
+                torch.cuda.synchronize()
+                tbest = min(tbest, e0.elapsed_time(e1) / a.iters)
+            print(f"    library (torch linear, bias, {a.dtype} out): {tbest * 1e3:7.1f} us {fl / tbest / 1e9:7.1f} TF/s", flush=True)
         print(f"{name} M={M} N={N} K={K} epi={epi}: " + "  ".join(f"v{v}: {best[v] * 1e3:7.1f} us {fl / best[v] / 1e9:7.1f} TF/s" for v in variants), flush=True)
         for v in variants:
             total[v] += best[v]
