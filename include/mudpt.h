@@ -161,9 +161,10 @@ int mudpt_layernorm_bwd(int32_t dtype, const void* dy, int32_t lddy, int32_t dy_
 int mudpt_attention_padded_len(int32_t L);
 int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H,
                         int32_t causal, void* stream);
-/* causal: bit 0 = causal mask.  Kernel choice (tests / A-B; default: the fused single pass over Q, K, V, dO -- delta stays on chip --
- * for padded lengths <= 96, the dQ kernel + dK/dV kernel pair above that): bit 1 = force the two kernels, bit 3 = force the fused pass,
- * bit 2 = force the fused pass with two 16-row blocks per wave. */
+/* causal: bit 0 = causal mask.  Kernel choice (tests / A-B).  Default: padded length <= 96 (the text tower): the fused two-sweep pass over
+ * resident Q, K, V, dO; longer non-causal sequences up to 224 (the vision tower): the single-sweep kernel (S, dP, exp computed once, dS
+ * crosses LDS for dQ); otherwise the dQ kernel + dK/dV kernel pair (delta through `delta`).  bit 1 = force the two kernels, bit 3 = force the
+ * fused two-sweep pass, bit 2 = the same with two 16-row blocks per wave, bit 4 = force the single sweep (non-causal, L <= 224). */
 int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                         float* delta, void* dqkv, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream);
 /* LayerNorm forward with everything the transformer block fuses into it (clip/model.py:281-301): v = x[r] + add[r] (fp32 add or T

@@ -715,6 +715,173 @@ __global__ __launch_bounds__(NC * 64 * W2) void attn_bwd_fused_kernel(AttnArgs p
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward, single sweep: S, P, dP, dS computed ONCE per (query, key); dS crosses LDS for dQ
+// ------------------------------------------------------------------------------------------------
+// The kernels above are bound by instruction issue (VALU ~ MFMA ~ LDS issue), not by memory, and both the dQ pass and the dK/dV pass
+// recompute S = Q K^T, dP = dO V^T and the exponentials: 8 of their 20 MFMAs per 16 x 32 tile and half of their VALU work are done twice.
+// This kernel runs the dK/dV sweep ("key on the lane": wave w owns key block w, K / V fragments in registers, Q / dO images in LDS)
+// and stores every dS tile, already rounded to T for the dK product, into an LDS image DS[key][query]; afterwards wave w computes
+// dQ of query block w = sum over ALL keys of dS[q, key] K[key, :] from that image (hardware-transposed reads give the operand with the
+// query on the lane) and a K image that is DMA-ed into the Q image's place once the sweep is over.  No atomics, no cross-wave
+// reduction: every sum has one owner and a fixed order (bitwise reproducible).  delta = rowsum(dO * O) is computed by the owner of
+// the query block before the sweep and stays in LDS.
+// LDS at Lp = 224: Q and dO images 2 x 28 KB + DS 224 x 224 x 2 B = 98 KB + statistics = 155.8 KB: one workgroup of 2 NC waves per CU.
+// DS image: panels of 32 queries, [panel][key][32 queries] with 64-byte rows; the two 32-byte halves of a row are swapped for keys
+// with bit 2 set, which makes the transposed 4-key x 16-query block reads conflict-free.
+template <int LP>
+__device__ inline int ds_off(int key, int q) {  // byte offset of element (key, q); q & 3 == 0 for the 8-byte accesses
+    return (q >> 5) * (LP * 64) + key * 64 + ((((q >> 4) & 1) ^ ((key >> 2) & 1)) << 5) + (q & 15) * 2;
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(NC * 128) void attn_bwd_sweep_kernel(AttnArgs p, const void* fwd_out, int dbg) {
+    using A = Attn<T>;
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    using vec4 = typename T::vec4;
+    constexpr int Lp = NC * 32, NW = NC * 2, NT = NW * 64, IMG = Lp * 128, DSB = Lp * Lp * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const elem* Qs = (const elem*)smem;           // Q image during the sweep, K image afterwards
+    const elem* Gs = (const elem*)(smem + IMG);   // dO image
+    char* DS = smem + 2 * IMG;
+    float* lse_s = (float*)(smem + 2 * IMG + DSB);  // [Lp] -lse log2(e) (-inf for padded queries)
+    float* del_s = lse_s + Lp;                      // [Lp] delta
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = blockIdx.x, b = pair / p.H, hd = pair - b * p.H;
+    const int HD = p.H * 64, L = p.L;
+    const size_t ld = (size_t)3 * HD;
+    const size_t ldof = p.ld_out ? (size_t)p.ld_out : (size_t)HD;
+    const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
+    const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
+    const elem* Of = (const elem*)fwd_out + (size_t)b * L * ldof + hd * 64;
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.qkv), 0, (int)((size_t)p.B * L * ld * 2), 0x00020000);
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dout), 0, (int)((size_t)p.B * L * HD * 2), 0x00020000);
+    const unsigned lane_q = (unsigned)(((size_t)(lane >> 3) * ld + (size_t)(((lane & 7) ^ (lane >> 3)) << 3)) * 2);
+    const unsigned lane_g = (unsigned)(((size_t)(lane >> 3) * HD + (size_t)(((lane & 7) ^ (lane >> 3)) << 3)) * 2);
+    const unsigned baseq = (unsigned)(((size_t)b * L * ld + (size_t)hd * 64) * 2), baseg = (unsigned)(((size_t)b * L * HD + (size_t)hd * 64) * 2);
+    using lds_ptr = __attribute__((address_space(3))) void*;
+
+    // ---- loads: Q and dO images by LDS-DMA (4 row groups of 8 rows per wave), this wave's K / V fragments, and the O / dO fragments
+    // of its query block for delta
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = wave * 4 + k, img = j / (Lp / 8), rg = j - img * (Lp / 8);
+        if (img == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr)(smem + rg * 1024), 16, (int)(baseq + lane_q + (unsigned)(rg * 8) * (unsigned)(ld * 2)), 0, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr)(smem + IMG + rg * 1024), 16, (int)(baseg + lane_g + (unsigned)(rg * 8) * (unsigned)(HD * 2)), 0, 0, 0);
+    }
+    const int nb16 = (L + 15) >> 4;
+    const int row = wave * 16 + c;  // this lane's key (sweep) and query (delta, final phase)
+    const vec8 k0 = A::grow(base + HD, ld, row, L, 0, lane), k1 = A::grow(base + HD, ld, row, L, 1, lane);
+    const vec8 v0 = A::grow(base + 2 * HD, ld, row, L, 0, lane), v1 = A::grow(base + 2 * HD, ld, row, L, 1, lane);
+    {
+        const vec8 g0 = A::grow(dO, HD, row, L, 0, lane), g1 = A::grow(dO, HD, row, L, 1, lane);
+        const vec8 o0 = A::grow(Of, ldof, row, L, 0, lane), o1 = A::grow(Of, ldof, row, L, 1, lane);
+        const float lse_q = row < L ? p.lse[(size_t)pair * Lp + row] : 0.f;
+        // DS rows of the key blocks that hold no real key are never written by a sweep: they must read as zero
+        for (int i = tid; i < (Lp - nb16 * 16) * NC * 4; i += NT) {  // (Lp - 16 nb16) keys x NC panels x 64 bytes, 16 bytes per thread
+            const int chunk = i & 3, rp = i >> 2, key = nb16 * 16 + rp % (Lp - nb16 * 16), panel = rp / (Lp - nb16 * 16);
+            *(f32x4*)(DS + panel * (Lp * 64) + key * 64 + chunk * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float delta = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) delta += (float)g0[i] * (float)o0[i] + (float)g1[i] * (float)o1[i];
+        delta = group_sum(delta);
+        if (g == 0) {
+            del_s[row] = delta;
+            lse_s[row] = row < L ? -lse_q * LOG2E : -INFINITY;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- sweep: dK, dV of key block `wave`; dS -> DS -------------------------------------------------------------------------
+    if (wave < nb16 && !(dbg & 1)) {
+        const bool kvalid = row < L;
+        f32x4 dK[4], dV[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int qc = 0; qc < NC; ++qc) {  // fully unrolled: every LDS address becomes a loop-invariant lane base + an immediate offset
+            f32x4 P[2], dS[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qt = 2 * qc + t;
+                const f32x4 nl = *(const f32x4*)(lse_s + qt * 16 + 4 * g);
+                const f32x4 d4 = *(const f32x4*)(del_s + qt * 16 + 4 * g);
+                f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = -d4;
+                S = T::mfma16(A::rows(Qs, qt * 16, 0, lane), k0, S);
+                S = T::mfma16(A::rows(Qs, qt * 16, 1, lane), k1, S);
+                dP = T::mfma16(A::rows(Gs, qt * 16, 0, lane), v0, dP);
+                dP = T::mfma16(A::rows(Gs, qt * 16, 1, lane), v1, dP);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // padded queries have nl = -inf -> p = 0; padded keys (whole lanes) are zeroed below
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nl[r]));
+                    P[t][r] = pr;
+                    dS[t][r] = pr * dP[r];  // 1 / sqrt(d) applied at the stores
+                }
+            }
+            const vec8 pb = A::pack2(P[0], P[1]), db = A::pack2(dS[0], dS[1]);
+            // dS of this lane's key for queries 32 qc + 4 g .. + 3 (tile 2 qc) and 32 qc + 16 + 4 g .. (tile 2 qc + 1): 8 bytes each
+            {
+                vec4 lo = {db[0], db[1], db[2], db[3]}, hi = {db[4], db[5], db[6], db[7]};
+                if (!kvalid) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { lo[i] = (elem)0.f; hi[i] = (elem)0.f; }
+                }
+                *(vec4*)(DS + ds_off<Lp>(row, 32 * qc + 4 * g)) = lo;
+                *(vec4*)(DS + ds_off<Lp>(row, 32 * qc + 16 + 4 * g)) = hi;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dV[dt] = T::mfma16(A::cols(Gs, qc * 32, dt * 16, lane), pb, dV[dt]);
+                dK[dt] = T::mfma16(A::cols(Qs, qc * 32, dt * 16, lane), db, dK[dt]);
+            }
+        }
+        if (kvalid) {
+            elem* ok = (elem*)p.dqkv + ((size_t)b * L + row) * ld + HD + hd * 64;
+            A::store_t(ok, dK, 0.125f, lane);
+            A::store_t(ok + HD, dV, 1.f, lane);
+        }
+    }
+    __syncthreads();  // DS is complete and nobody reads the Q image any more
+    if (dbg & 2) return;
+
+    // ---- the K image takes the Q image's place (2 row groups per wave) -------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int rg = wave * 2 + k;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr)(smem + rg * 1024), 16, (int)(baseq + (unsigned)(HD * 2) + lane_q + (unsigned)(rg * 8) * (unsigned)(ld * 2)), 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- dQ of query block `wave`: dQ^T[d, q] = sum over keys K[key, d] dS[q, key] --------------------------------------------
+    if (wave < nb16 && !(dbg & 4)) {
+        f32x4 dQ[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // transposed block read of DS: lane i of 16-lane group g addresses key row 32 kc + 4 g + (i >> 2), queries 16 wave + 4 (i & 3) .. + 3
+        // and receives query 16 wave + i of the block's four keys; the second read takes the keys 16 further (same swizzle)
+        const char* dsp = DS + ds_off<Lp>(4 * g + (c >> 2), 16 * wave + 4 * (c & 3));
+#pragma unroll
+        for (int kc = 0; kc < NC; ++kc) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dsp + kc * 32 * 64));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dsp + kc * 32 * 64 + 16 * 64));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const vec8 db = __builtin_bit_cast(vec8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dQ[dt] = T::mfma16(A::cols(Qs, kc * 32, dt * 16, lane), db, dQ[dt]);
+        }
+        if (row < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + row) * ld + hd * 64, dQ, 0.125f, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Long sequences (L > 224: ViT-L/14@336 has 577 + n_ctx vision tokens, BASELINE configs[4]): the other operand no longer
 // fits in LDS as a whole, so it streams through a 64-row stage and the forward keeps a running (online) softmax.  Same
 // fragment conventions and inner products as the whole-sequence kernels above; one workgroup = 4 waves = 64 rows of the
@@ -1060,12 +1227,27 @@ static int bwd_fused_cfg(const AttnArgs& a, hipStream_t s, const LaunchProf* pro
     return MUDPT_OK;
 }
 
+// single sweep (non-causal, whole sequence on chip, one workgroup per pair)
+template <typename T, int NC>
+static int bwd_sweep_cfg(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
+    constexpr int lds = 2 * NC * 32 * 128 + NC * 32 * NC * 32 * 2 + 2 * NC * 32 * 4;
+    static_assert(lds <= 163840, "attn_bwd_sweep_kernel: LDS");
+    auto kern = attn_bwd_sweep_kernel<T, NC>;
+    static PerDevice pd;
+    const int dev = current_device();
+    if (!pd.done[dev]) { if (int e = set_lds(kern, lds)) return e; pd.done[dev] = true; }
+    MUDPT_LAUNCH(kern, dim3(a.B * a.H), dim3(NC * 128), lds, s, prof, a, (const void*)a.out, a.dbg);
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
 template <typename T, bool BWD>
 static int dispatch(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
     if (a.L > 224) return tiled_launch<T, BWD>(a, s, prof);  // the other operand streams through 64-row stages
     const int nc = attn_padded_len(a.L) / 32;
 #define MUDPT_ATTN_CASE(N)                                                                     \
     case N:                                                                                    \
+        if (BWD && !a.sel_rows && !a.causal && !a.two_kernels && !a.force_fused && (N >= 4 || a.sweep)) return bwd_sweep_cfg<T, N>(a, s, prof); \
         if (BWD && !a.sel_rows && !a.two_kernels && (N <= 3 || a.force_fused)) {                   \
             if (a.fused_w1) return a.causal ? bwd_fused_cfg<T, N, true, 1>(a, s, prof) : bwd_fused_cfg<T, N, false, 1>(a, s, prof); \
             return a.causal ? bwd_fused_cfg<T, N, true, 2>(a, s, prof) : bwd_fused_cfg<T, N, false, 2>(a, s, prof); \

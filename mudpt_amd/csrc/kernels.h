@@ -93,6 +93,8 @@ struct AttnArgs {
     // bwd, optional: dout is zero except on ONE row per sequence, token row sel_rows[b] (the last block: only the CLS / EOT row of its
     // output is used): dQ is computed for that row's 16-query block only (zero elsewhere) and dK / dV sum over that block's chunk
     const int* sel_rows = nullptr;
+    int dbg = 0;                // timing ablations of the sweep kernel (diagnostic)
+    bool sweep = false;         // bwd, non-causal: the single-sweep kernel (S / dP computed once, dS through LDS)
     bool force_fused = false;   // bwd: the fused single pass also where the dispatcher prefers the two kernels (NC > 3; A/B, tests)
     bool fused_w1 = false;      // bwd, fused form: NC waves with two 16-row blocks each instead of 2 NC waves with one (A/B)
     bool two_kernels = false;   // bwd: the dQ kernel + dK/dV kernel pair instead of the fused single pass (A/B runs, tests)

@@ -1297,6 +1297,6 @@ extern "C" int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, fl
 extern "C" int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int32_t B,
                                    int32_t L, int32_t H, int32_t causal, void* stream) {
     AttnArgs a; a.qkv = qkv; a.out = (void*)out; a.dout = dout; a.lse = (float*)lse; a.delta = delta; a.dqkv = dqkv; a.B = B; a.L = L; a.H = H;
-    a.causal = (causal & 1) != 0; a.two_kernels = (causal & 2) != 0; a.fused_w1 = (causal & 4) != 0; a.force_fused = (causal & 12) != 0;
+    a.causal = (causal & 1) != 0; a.two_kernels = (causal & 2) != 0; a.fused_w1 = (causal & 4) != 0; a.force_fused = (causal & 12) != 0; a.sweep = (causal & 16) != 0; a.dbg = (causal >> 8) & 0xff;
     return launch_attn_bwd(dtype, a, (hipStream_t)stream);
 }

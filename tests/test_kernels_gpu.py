@@ -373,12 +373,19 @@ def test_attention_fwd_bwd(lib, dtype, B, L, H, causal):
     ok(lib, lib.mudpt_attention_bwd(dt, P(qc), P(out), P(doc), P(lse), P(delta), P(again), B, L, H, int(causal), None))
     torch.cuda.synchronize()
     assert torch.equal(again, dqkv)
-    for form in (2, 4, 8):
-        other = torch.zeros_like(dqkv)
+    # bit 4: the single-sweep kernel (non-causal, L <= 224): S / dP / exp computed once, dS rounded to T crosses LDS for dQ -- the same
+    # rounding point as the other forms (they round dS to T for the dQ product too)
+    forms = (2, 4, 8) if causal or L > 224 else (2, 4, 8, 16)
+    for form in forms:
+        other = torch.full_like(dqkv, float("nan"))
         ok(lib, lib.mudpt_attention_bwd(dt, P(qc), P(out), P(doc), P(lse), P(delta), P(other), B, L, H, int(causal) | form, None))
         torch.cuda.synchronize()
         torch.testing.assert_close(other.cpu().float(), dref, atol=12 * EPS[dtype] * scale, rtol=8 * EPS[dtype])
         torch.testing.assert_close(other.float(), dqkv.float(), atol=2 * EPS[dtype] * scale, rtol=2 * EPS[dtype])
+        twice = torch.zeros_like(dqkv)
+        ok(lib, lib.mudpt_attention_bwd(dt, P(qc), P(out), P(doc), P(lse), P(delta), P(twice), B, L, H, int(causal) | form, None))
+        torch.cuda.synchronize()
+        assert torch.equal(twice, other), form
 
 
 def test_attention_softmax_extremes(lib):

@@ -26,7 +26,7 @@ def main():
         def bwd(form=0):
             assert lib.mudpt_attention_bwd(0, P(qkv), P(out), P(dout), P(lse), P(delta), P(dqkv), B, L, H, causal | form, None) == 0
         res = []
-        for fn in (fwd, lambda: bwd(8), lambda: bwd(2), lambda: bwd(4)):
+        for fn in (fwd, lambda: bwd(8), lambda: bwd(2), lambda: bwd(4), lambda: bwd(0 if causal else 16)):
             fn()
             torch.cuda.synchronize()
             best = 1e9
@@ -40,7 +40,7 @@ def main():
                 best = min(best, e0.elapsed_time(e1) / 10)
             res.append(best)
         fl = 4.0 * B * H * L * L * 64
-        print(f"{name}: fwd {res[0] * 1e3:7.1f} us ({fl / res[0] / 1e9:6.1f} TF/s)   bwd fused {res[1] * 1e3:7.1f} us ({2.5 * fl / res[1] / 1e9:6.1f} TF/s algorithmic)   two kernels {res[2] * 1e3:7.1f} us   fused, 2 blocks / wave {res[3] * 1e3:7.1f} us", flush=True)
+        print(f"{name}: fwd {res[0] * 1e3:7.1f} us ({fl / res[0] / 1e9:6.1f} TF/s)   bwd fused {res[1] * 1e3:7.1f} us ({2.5 * fl / res[1] / 1e9:6.1f} TF/s algorithmic)   two kernels {res[2] * 1e3:7.1f} us   fused, 2 blocks / wave {res[3] * 1e3:7.1f} us   {'default' if causal else 'single sweep'} {res[4] * 1e3:7.1f} us", flush=True)
 
 
 if __name__ == "__main__":
