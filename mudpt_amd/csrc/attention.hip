@@ -726,6 +726,12 @@ __global__ __launch_bounds__(NC * 64 * W2) void attn_bwd_fused_kernel(AttnArgs p
 // reduction: every sum has one owner and a fixed order (bitwise reproducible).  delta = rowsum(dO * O) is computed by the owner of
 // the query block before the sweep and stays in LDS.
 // LDS at Lp = 224: Q and dO images 2 x 28 KB + DS 224 x 224 x 2 B = 98 KB + statistics = 155.8 KB: one workgroup of 2 NC waves per CU.
+// Measured (round 2, B 256 / L 201 / H 12, bf16): 216 us against 261 us for the two kernels.  Timing ablations of this kernel (phases
+// skipped by a run-time flag): loads alone 81 us (474 MB at 5.8 TB/s: that phase is HBM-bound), + sweep 186 us, all 235 us -- a CU
+// runs its phases one after the other.  Two attempts to overlap them were SLOWER and are not kept: a persistent form with the K
+// image resident, the query range swept in two halves (half the dS image) and the next pair's images / fragments prefetched: 255 us
+// (252 us with the workgroups' starts staggered; its dQ phases keep only 8 and 5 of the 14 waves busy and the persistent
+// workgroups load and compute in lockstep), and fully unrolled loops with immediate LDS offsets (214 us: not the instruction count).
 // DS image: panels of 32 queries, [panel][key][32 queries] with 64-byte rows; the two 32-byte halves of a row are swapped for keys
 // with bit 2 set, which makes the transposed 4-key x 16-query block reads conflict-free.
 template <int LP>
@@ -734,7 +740,7 @@ __device__ inline int ds_off(int key, int q) {  // byte offset of element (key, 
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(NC * 128) void attn_bwd_sweep_kernel(AttnArgs p, const void* fwd_out, int dbg) {
+__global__ __launch_bounds__(NC * 128) void attn_bwd_sweep_kernel(AttnArgs p, const void* fwd_out) {
     using A = Attn<T>;
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(NC * 128) void attn_bwd_sweep_kernel(AttnArgs p, co
     __syncthreads();
 
     // ---- sweep: dK, dV of key block `wave`; dS -> DS -------------------------------------------------------------------------
-    if (wave < nb16 && !(dbg & 1)) {
+    if (wave < nb16) {
         const bool kvalid = row < L;
         f32x4 dK[4], dV[4];
 #pragma unroll
@@ -849,7 +855,6 @@ __global__ __launch_bounds__(NC * 128) void attn_bwd_sweep_kernel(AttnArgs p, co
         }
     }
     __syncthreads();  // DS is complete and nobody reads the Q image any more
-    if (dbg & 2) return;
 
     // ---- the K image takes the Q image's place (2 row groups per wave) -------------------------------------------------------
 #pragma unroll
@@ -861,7 +866,7 @@ __global__ __launch_bounds__(NC * 128) void attn_bwd_sweep_kernel(AttnArgs p, co
     __syncthreads();
 
     // ---- dQ of query block `wave`: dQ^T[d, q] = sum over keys K[key, d] dS[q, key] --------------------------------------------
-    if (wave < nb16 && !(dbg & 4)) {
+    if (wave < nb16) {
         f32x4 dQ[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1236,7 +1241,7 @@ static int bwd_sweep_cfg(const AttnArgs& a, hipStream_t s, const LaunchProf* pro
     static PerDevice pd;
     const int dev = current_device();
     if (!pd.done[dev]) { if (int e = set_lds(kern, lds)) return e; pd.done[dev] = true; }
-    MUDPT_LAUNCH(kern, dim3(a.B * a.H), dim3(NC * 128), lds, s, prof, a, (const void*)a.out, a.dbg);
+    MUDPT_LAUNCH(kern, dim3(a.B * a.H), dim3(NC * 128), lds, s, prof, a, (const void*)a.out);
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
 }

@@ -93,7 +93,6 @@ struct AttnArgs {
     // bwd, optional: dout is zero except on ONE row per sequence, token row sel_rows[b] (the last block: only the CLS / EOT row of its
     // output is used): dQ is computed for that row's 16-query block only (zero elsewhere) and dK / dV sum over that block's chunk
     const int* sel_rows = nullptr;
-    int dbg = 0;                // timing ablations of the sweep kernel (diagnostic)
     bool sweep = false;         // bwd, non-causal: the single-sweep kernel (S / dP computed once, dS through LDS)
     bool force_fused = false;   // bwd: the fused single pass also where the dispatcher prefers the two kernels (NC > 3; A/B, tests)
     bool fused_w1 = false;      // bwd, fused form: NC waves with two 16-row blocks each instead of 2 NC waves with one (A/B)
@@ -150,6 +149,11 @@ struct HeadArgs {
 };
 int launch_head_fwd(const HeadArgs& a, hipStream_t s);
 int launch_head_bwd(const HeadArgs& a, hipStream_t s);
+// Fused form (head.hip): the logit contraction on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32), cross-entropy and dlogits
+// in the workgroup that made the logit rows.  a.txt == null: keep the normalised text features of the previous call.
+bool head_fused_fits(const HeadArgs& a, bool train);
+int launch_head_fused_fwd(const HeadArgs& a, hipStream_t s);
+int launch_head_fused_train(const HeadArgs& a, hipStream_t s);  // logits + loss + dimg + dtxt (gradients of the raw features)
 // CoCoOp (trainers/cocoop.py): per-image text features.  txt / txt_n / txt_inv / dtxt have B * C rows (row i * C + c).
 int launch_pair_head_fwd(const HeadArgs& a, hipStream_t s);
 int launch_pair_head_bwd(const HeadArgs& a, hipStream_t s);  // loss, dlogits, dtxt (gradient of the raw text features)

@@ -954,7 +954,7 @@ static int cocoop_forward_backward(mudpt_model* m, const float* images, const in
     return MUDPT_OK;
 }
 
-static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t s, bool reuse_text = false) {
+static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t s, bool reuse_text = false, bool skip_head = false) {
     if (m->cocoop) return cocoop_forward(m, images, B, s);
     const mudpt_config& c = m->cfg;
     const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, C = c.n_cls;
@@ -993,9 +993,15 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
     TRY(vision_forward(m, images, B, s));
     // -- cosine logits, trainers/mudpt.py:178-182 (needs both towers)
     if (!reuse_text) HIP_TRY(hipStreamWaitEvent(s, m->ev_join, 0));
+    if (skip_head) return MUDPT_OK;  // the training step runs the fused forward + cross-entropy + backward head itself
     HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.scale = m->scale; h.logits = m->logits; h.img_n = m->img_n; h.txt_n = m->txt_n;
     h.img_inv = m->img_inv; h.txt_inv = m->txt_inv; h.B = B; h.C = C; h.e = e;
-    TRY(launch_head_fwd(h, s));
+    if (head_fused_fits(h, false)) {
+        if (reuse_text) h.txt = nullptr;  // the normalised text features of the previous call are still in m->txt_n
+        TRY(launch_head_fused_fwd(h, s));
+    } else {
+        TRY(launch_head_fwd(h, s));
+    }
     return MUDPT_OK;
 }
 
@@ -1024,8 +1030,9 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, C = c.n_cls;
     const int Lv = m->vis.L, Lt = m->txt.L;
     float *Pm = m->params, *G = m->grads;
-    TRY(forward_impl(m, images, B, s));
-    if (logits) HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));
+    HeadArgs hf; hf.B = B; hf.C = C; hf.e = e;
+    const bool fused_head = head_fused_fits(hf, true);
+    TRY(forward_impl(m, images, B, s, false, fused_head));
     HIP_TRY(hipMemsetAsync(G, 0, m->total * 4, s));
 
     // -- head: cross-entropy (mean) + cosine logits backward, trainers/mudpt.py:178-182,250
@@ -1037,7 +1044,8 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     // the towers multiply by `unscale`; everything after them is fp32 and linear.
     const float unscale = grad_scale / ((float)B * m->loss_scale);
     h.grad_scale = m->loss_scale * (float)B; h.B = B; h.C = C; h.e = e;
-    TRY(launch_head_bwd(h, s));
+    if (fused_head) TRY(launch_head_fused_train(h, s)); else TRY(launch_head_bwd(h, s));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(loss, m->loss, 4, hipMemcpyDeviceToDevice, s));
 
     // -- text tower backward, on the side stream (enqueued first; joins before the prompt-learner backward).  It only
@@ -1275,8 +1283,12 @@ extern "C" int mudpt_head(const float* img, const float* txt, const int64_t* lab
     HeadArgs h; h.img = img; h.txt = txt; h.labels = labels; h.scale = scale; h.logits = logits; h.loss = loss; h.dimg = dimg; h.dtxt = dtxt;
     h.img_n = scratch; h.txt_n = h.img_n + (size_t)B * e; h.img_inv = h.txt_n + (size_t)C * e; h.txt_inv = h.img_inv + B;
     h.dlogits = h.txt_inv + C; h.row_loss = h.dlogits + (size_t)B * C; h.grad_scale = grad_scale; h.B = B; h.C = C; h.e = e;
-    int rc = launch_head_fwd(h, s);
-    if (!rc && labels) rc = launch_head_bwd(h, s);
+    int rc;
+    if (head_fused_fits(h, labels != nullptr)) rc = labels ? launch_head_fused_train(h, s) : launch_head_fused_fwd(h, s);
+    else {
+        rc = launch_head_fwd(h, s);
+        if (!rc && labels) rc = launch_head_bwd(h, s);
+    }
     (void)hipStreamSynchronize(s);
     (void)hipFree(scratch);
     return rc;
@@ -1297,6 +1309,6 @@ extern "C" int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, fl
 extern "C" int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int32_t B,
                                    int32_t L, int32_t H, int32_t causal, void* stream) {
     AttnArgs a; a.qkv = qkv; a.out = (void*)out; a.dout = dout; a.lse = (float*)lse; a.delta = delta; a.dqkv = dqkv; a.B = B; a.L = L; a.H = H;
-    a.causal = (causal & 1) != 0; a.two_kernels = (causal & 2) != 0; a.fused_w1 = (causal & 4) != 0; a.force_fused = (causal & 12) != 0; a.sweep = (causal & 16) != 0; a.dbg = (causal >> 8) & 0xff;
+    a.causal = (causal & 1) != 0; a.two_kernels = (causal & 2) != 0; a.fused_w1 = (causal & 4) != 0; a.force_fused = (causal & 12) != 0; a.sweep = (causal & 16) != 0;
     return launch_attn_bwd(dtype, a, (hipStream_t)stream);
 }

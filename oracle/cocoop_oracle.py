@@ -106,22 +106,33 @@ def text_tower(cfg: O.Config, sd: Dict[str, Tensor], prompts: Tensor, eot: Tenso
 
 
 def forward(cfg: O.Config, sd: Dict[str, Tensor], params: Dict[str, Tensor], class_embedding: Tensor, eot: Tensor,
-            images: Tensor) -> Tensor:
-    """trainers/cocoop.py:178-195 -> logits [B, C]."""
+            images: Tensor, taps: Dict[str, Tensor] = None) -> Tensor:
+    """trainers/cocoop.py:178-195 -> logits [B, C].  taps (tests): receives the text-tower input "prompts" [B * C, ctx_len, d_t] with its
+    gradient retained, i.e. the per-(image, class) terms whose sums are the ctx / meta_net gradients."""
     B, C = images.shape[0], class_embedding.shape[0]
     img = vision_tower(cfg, sd, images)
     img = img / img.norm(dim=-1, keepdim=True)
     prompts = prompts_for(cfg, params, class_embedding, img).reshape(B * C, cfg.ctx_len, cfg.t_width)
+    if taps is not None and prompts.requires_grad:
+        prompts.retain_grad()
+        taps["prompts"] = prompts
     txt = text_tower(cfg, sd, prompts, eot.repeat(B)).reshape(B, C, -1)
     txt = txt / txt.norm(dim=-1, keepdim=True)
     return sd["logit_scale"].exp() * torch.einsum("be,bce->bc", img, txt)
 
 
 def forward_backward(cfg: O.Config, sd: Dict[str, Tensor], params: Dict[str, Tensor], class_embedding: Tensor, eot: Tensor,
-                     images: Tensor, labels: Tensor):
-    """trainers/cocoop.py:196-197 + :258-261: mean cross-entropy and its gradient w.r.t. the 5 trainables."""
+                     images: Tensor, labels: Tensor, taps: Dict[str, Tensor] = None):
+    """trainers/cocoop.py:196-197 + :258-261: mean cross-entropy and its gradient w.r.t. the 5 trainables.
+    taps (tests): "dprompts" [B, C, ctx_len, d_t] = gradient w.r.t. every (image, class) prompt (the terms the gradients sum over)."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    logits = forward(cfg, sd, leaf, class_embedding, eot, images)
+    inner = {} if taps is not None else None
+    logits = forward(cfg, sd, leaf, class_embedding, eot, images, inner)
     loss = F.cross_entropy(logits, labels.long())
-    grads = torch.autograd.grad(loss, [leaf[k] for k in TRAINABLE_ORDER])
+    if taps is None:
+        grads = torch.autograd.grad(loss, [leaf[k] for k in TRAINABLE_ORDER])
+    else:
+        loss.backward()
+        grads = [leaf[k].grad for k in TRAINABLE_ORDER]
+        taps["dprompts"] = inner["prompts"].grad.detach().reshape(images.shape[0], class_embedding.shape[0], cfg.ctx_len, cfg.t_width)
     return loss.detach(), logits.detach(), dict(zip(TRAINABLE_ORDER, grads))

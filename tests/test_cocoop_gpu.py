@@ -14,11 +14,27 @@ pytestmark = pytest.mark.gpu
 LOGIT_RMS = {"fp16": 5e-4, "bf16": 1.6e-2}
 LOGIT_ATOL = {"fp16": 1e-3, "bf16": 3.2e-2}
 TINY_SLACK = 1.5
-# Gradients, relative to each tensor's RMS.  ctx behaves like MuDPT's prompts.  meta_net's gradients come from d bias_i = sum over the
-# C class prompts (and n_ctx rows) of the text-input gradient, and sum_c dlogits[i, c] = 0: the per-class terms nearly cancel, so
-# the T-precision rounding of each term is amplified relative to the surviving signal.  Bounds: RMS error / max error.
-GRAD_RMS = {"fp16": 2e-2, "bf16": 1.5e-1}
-GRAD_MAX = {"fp16": 8e-2, "bf16": 1.2}  # bf16 (8-bit significand): single elements of the cancelling sums are only sanity-bounded
+# Gradients.  Error model: every gradient here is a SUM of per-(image, class) terms -- d ctx = sum_i sum_c T[i, c], d bias_i = sum_c T[i, c]
+# (T[i, c] = the n_ctx context rows of the text-input gradient of prompt (i, c)), and meta_net's gradients are linear images of d bias.
+# Each term comes out of the T-precision text-tower backward with a relative error delta_T (the same figure the non-cancelling MuDPT
+# gradients are held to: tests/test_model_gpu.py GRAD_RTOL); the errors of different terms are independent, so the error of a sum has
+# RMS delta_T * sqrt(sum T^2), while the signal is |sum T|.  Because sum_c dlogits[i, c] = 0 the terms nearly cancel:
+# kappa = ||sqrt(sum T^2)|| / ||sum T|| >= 1 measures by how much (computed below from the ORACLE's own terms, per tensor).  Bounds:
+# RMS error <= delta_T * kappa * rms(gradient); single elements <= 4 * delta_T * kappa * max|gradient| (meta_net's weight gradients
+# are outer products with heavy tails: an element's error scales with the element, not with the tensor's RMS).
+# delta_T = relative error of ONE term out of the 12-layer T-precision backward: measured 0.8-1.6e-3 (fp16) and 1.1-2.5e-2 (bf16) on the
+# two fixtures (the printed rms err / kappa); the bounds leave a factor 1.6-2.5.
+DELTA_T = {"fp16": 4e-3, "bf16": 4e-2}
+
+
+def cancellation_factors(cfg, dprompts):
+    """kappa per trainable from the per-(image, class) terms T = dprompts[:, :, 1 : 1 + n_ctx] ([B, C, n, d])."""
+    T = dprompts[:, :, 1:1 + cfg.n_ctx].double()
+    quad_ctx, sig_ctx = T.pow(2).sum((0, 1)).sqrt(), T.sum((0, 1))          # [n, d]
+    quad_b, sig_b = T.pow(2).sum((1, 2)).sqrt(), T.sum((1, 2))              # [B, d]
+    k_ctx = (quad_ctx.norm() / sig_ctx.norm()).item()
+    k_b = (quad_b.norm() / sig_b.norm()).item()
+    return {"prompt_learner.ctx": k_ctx, "meta": k_b}
 
 
 def build(cfg, frozen, tokens, params, dtype, max_batch, knobs=None):
@@ -51,13 +67,18 @@ def test_logits_loss_grads_match_reference(case, dtype):
     assert torch.equal(logits2.cpu(), logits)  # same kernels, same order: bitwise
     assert abs(loss.item() - case.loss) <= slack * LOGIT_ATOL[dtype]
     got = {k: v.detach().cpu() for k, v in m.grads().items()}
+    taps = {}
+    CO.forward_backward(case.cfg, case.frozen, case.params, case.class_embedding, case.eot, case.images, case.labels, taps)
+    kappa = cancellation_factors(case.cfg, taps["dprompts"])
     bad = []
     for k in CO.TRAINABLE_ORDER:
         r = case.grad(k)
         rms_g = r.pow(2).mean().sqrt().item()
         e, er = (got[k] - r).abs().max().item(), (got[k] - r).pow(2).mean().sqrt().item()
-        print(f"{dtype} {k}: rms {rms_g:.3e} rms err {er / rms_g:.3e} max err {e / rms_g:.3e} (relative to rms)")
-        if er > GRAD_RMS[dtype] * rms_g + 1e-9 or e > GRAD_MAX[dtype] * rms_g + 1e-9:
+        kap = kappa.get(k, kappa["meta"])
+        bound, gmax = DELTA_T[dtype] * kap, r.abs().max().item()
+        print(f"{dtype} {k}: rms {rms_g:.3e} kappa {kap:.2f} rms err {er / rms_g:.3e} (bound {bound:.3e}) max err / max|g| {e / gmax:.3e} (bound {4 * bound:.3e})")
+        if er > bound * rms_g + 1e-9 or e > 4 * bound * gmax + 1e-9:
             bad.append(k)
     m.close()
     assert not bad, bad
@@ -80,7 +101,10 @@ def test_larger_batch_against_oracle_and_sgd(chunk):
     for step in range(2):
         loss, logits = m.forward_backward(images, labels, return_logits=True)
         ref_loss, ref_logits, ref = CO.forward_backward(cfg, frozen, p, emb, eot, images, labels)
-        assert (logits.cpu() - ref_logits).abs().max().item() <= 3e-3  # 66 logits of random (untrained) prompts; measured 2.2e-3
+        # logit error model: logit = scale * cos(img, txt); a relative feature error eps in a random direction changes the cosine of two
+        # e-dimensional unit vectors by ~eps / sqrt(e), so at equal eps the tiny shape (e = 128) is sqrt(512 / 128) = 2 x worse than
+        # ViT-B/16's 1e-3 (north_star), and CoCoOp's image-feature error enters twice (directly and through meta_net's context shift): 1.5 x
+        assert (logits.cpu() - ref_logits).abs().max().item() <= 1e-3 * (512 / cfg.embed_dim) ** 0.5 * 1.5
         assert abs(loss.item() - ref_loss.item()) <= 2e-3
         for k in CO.TRAINABLE_ORDER:
             r = ref[k]

@@ -38,8 +38,11 @@ def test_small_shapes_against_the_oracle(n_ctx, depth, batch, n_cls):
     m = build(cfg, frozen, tok, params, "fp16", batch)
     loss, logits = m.forward_backward(images, labels, return_logits=True)
     torch.cuda.synchronize()
-    assert (logits.cpu() - ref_logits).abs().max().item() <= 2e-3
-    assert abs(loss.item() - ref_loss.item()) <= 2e-3
+    # logit error model (tests/test_cocoop_gpu.py): a relative feature error eps moves the cosine of two e-dimensional unit vectors by
+    # ~eps / sqrt(e): the tiny shape (e = 128) gets sqrt(512 / 128) = 2 x ViT-B/16's 1e-3 (north_star)
+    tol = 1e-3 * (512 / cfg.embed_dim) ** 0.5
+    assert (logits.cpu() - ref_logits).abs().max().item() <= tol
+    assert abs(loss.item() - ref_loss.item()) <= tol
     for k, gr in m.grads().items():
         r = ref[k]
         assert r.shape == gr.shape, k
