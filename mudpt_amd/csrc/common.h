@@ -41,11 +41,18 @@ struct F16 {
     }
 };
 
+// sigmoid(1.702 u) = 1 / (1 + 2^(-1.702 log2(e) u)) from the two hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each) instead
+// of expf + an IEEE division: the division alone is ~10 VALU instructions (v_div_scale x 2, v_rcp, 5 fma, v_div_fmas, v_div_fixup), and a
+// 256 x 256 MLP tile evaluates this 65 536 times in an epilogue during which the matrix cores idle (measured: DESIGN.md 4).  The
+// result is rounded to T (8 / 11 bits) right away; u -> +-inf gives exactly 0 / 1.
+__device__ inline float sigmoid_1702(float u) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * u));
+}
 __device__ inline float quick_gelu(float u) {  // clip/model.py:173-175  x * sigmoid(1.702 x)
-    return u / (1.0f + __expf(-1.702f * u));
+    return u * sigmoid_1702(u);
 }
 __device__ inline float quick_gelu_grad(float u) {
-    float s = 1.0f / (1.0f + __expf(-1.702f * u));
+    const float s = sigmoid_1702(u);
     return s * (1.0f + 1.702f * u * (1.0f - s));
 }
 
