@@ -20,18 +20,24 @@ namespace mudpt {
 constexpr int HEAD_ROWS = 16, HEAD_WAVES = 8, HEAD_RPW = HEAD_ROWS / HEAD_WAVES;  // 16 rows per workgroup, 8 waves, 2 rows per wave in the row-wise phases
 
 // acc[t] += A[16, K] . B[K, 16 tile t]: A from `a_row` (this lane's row, k contiguous: LDS or global), B rows from `b_base + k * ldb`
-// (k-major operand: element (k, col) at b[k * ldb + col]); K a multiple of 4; rows of B beyond k_valid read as zero.
+// (k-major operand: element (k, col) at b[k * ldb + col]); K a multiple of 16; rows of B beyond k_valid read as zero.
 template <int NT>
 __device__ inline void mfma_kmajor(f32x4 (&acc)[NT], const float* a_row, int a_stride_k, const float* b_base, size_t ldb, const int (&col)[NT],
                                    const bool (&col_ok)[NT], int K, int k_valid, int g) {
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + g;
-        const float a = a_row[(size_t)k * a_stride_k];
+    // 4 steps' operands are requested before the first MFMA (the loop is otherwise one dependent memory round trip per step); K % 16 == 0
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float av[4], bv[4][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float b = (col_ok[t] && k < k_valid) ? b_base[(size_t)k * ldb + col[t]] : 0.f;
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + g;
+            av[u] = a_row[(size_t)k * a_stride_k];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bv[u][t] = (col_ok[t] && k < k_valid) ? b_base[(size_t)k * ldb + col[t]] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][t], acc[t], 0, 0, 0);
     }
 }
 
@@ -79,12 +85,19 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void head_rows_kernel(HeadArgs p, 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* ar = In + c * e + 4 * g;
         const float* br = p.txt_n + (size_t)(cls < C ? cls : 0) * e + 4 * g;
-        for (int j = 0; j < e; j += 16) {
-            const f32x4 a4 = *(const f32x4*)(ar + j);
-            f32x4 b4 = *(const f32x4*)(br + j);
-            if (cls >= C) b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < e; j0 += 128) {  // 8 float4 pairs requested before the first MFMA: the loads overlap instead of chaining
+            f32x4 a4[8], b4[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t], b4[t], acc, 0, 0, 0);
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 16 * u;
+                const bool in = j < e;
+                a4[u] = in ? *(const f32x4*)(ar + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+                b4[u] = (in && cls < C) ? *(const f32x4*)(br + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t], b4[u][t], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -168,14 +181,21 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void head_dtxt_kernel(HeadArgs p) 
         bool ok[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; col[t] = (et0 + t) * 16 + c; ok[t] = et0 + t < ne; }
-        for (int k0 = 0; k0 < Bpad; k0 += 4) {
-            const int k = k0 + g;
-            const float a = (k < B && cls < C) ? a_row[(size_t)k * C] : 0.f;
+        // the sum over the images is a latency chain (one dependent global round trip per step of 4 images): 8 steps' operands are
+        // requested before the first MFMA so the loads overlap; the MFMA order (images ascending) is unchanged
+        for (int k0 = 0; k0 < Bpad; k0 += 32) {
+            float av[8], bv[8][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float b = (ok[t] && k < B) ? p.img_n[(size_t)k * e + col[t]] : 0.f;
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 4 * u + g;
+                av[u] = (k < B && cls < C) ? a_row[(size_t)k * C] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[u][t] = (ok[t] && k < B) ? p.img_n[(size_t)k * e + col[t]] : 0.f;
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][t], acc[t], 0, 0, 0);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)

@@ -48,7 +48,7 @@ CLASSES = [  # (class, kernel-name regex, minimum grid size: the vision tower's 
     ("ln_fwd", r"^ln_fwd_kernel<.*false>", 1 << 20),
     ("ln_bwd", r"^ln_bwd_kernel<.*false>", 1 << 20),
     ("attn_fwd", r"^attn_fwd_kernel", 0),
-    ("attn_bwd", r"^attn_bwd_(dq|dkv|fused)_kernel<[^,]*, 7", 0),
+    ("attn_bwd", r"^attn_bwd_sweep_kernel<[^,]*, 7", 0),
 ]
 
 
