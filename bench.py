@@ -163,6 +163,18 @@ def main():
     classes, exec_flop = model.profile_read_classes() if not args.no_profile else ({}, 0.0)
     gemm_ms, gemm_flop, gemm_n = classes.get("gemm_pp", (0.0, 0.0, 0))
     model.profile(False)
+    # The HBM-bound kernel classes (LayerNorm, attention) are measured in their own short pass AFTER the timed region: an event pair costs
+    # ~5 us of queue time per bracketed launch, and bracketing all 157 big launches of a step slowed the timed steps by 0.8 ms (3 %).
+    hbm_steps = 0
+    if not args.no_profile and graph is None:
+        hbm_steps = max(2, min(5, args.steps))
+        model.profile(0b11110)
+        for _ in range(hbm_steps):
+            step()
+        fence()
+        hbm_classes, _ = model.profile_read_classes()
+        model.profile(False)
+        classes.update({k: v for k, v in hbm_classes.items() if k != "gemm_pp"})
     collective = None
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda")
@@ -230,8 +242,8 @@ def main():
                     continue
                 gbs = c_bytes / (c_ms * 1e-3) / 1e9
                 hbm[cls] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                            "algorithmic_bytes_per_launch": round(c_bytes / c_n), "launches_per_step": c_n // args.steps, "avg_launch_us": round(c_ms * 1e3 / c_n, 2),
-                            "ms_per_step": round(c_ms / args.steps, 3),
+                            "algorithmic_bytes_per_launch": round(c_bytes / c_n), "launches_per_step": c_n // hbm_steps, "avg_launch_us": round(c_ms * 1e3 / c_n, 2),
+                            "ms_per_step": round(c_ms / hbm_steps, 3),
                             "traffic": round(traffic_db[cls]["traffic_bytes_per_launch"]) if cls in traffic_db else None}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": round(pmc["traffic_bytes_per_launch"]) if pmc else None,
@@ -249,9 +261,10 @@ def main():
                                "step_achieved": round(step_flop / (ms * 1e-3) / 1e12, 1), "step_frac": round(step_flop / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4),
                                "executed_tflop_per_step": round(exec_flop / args.steps / 1e12, 3),
                                "executed_frac": round(exec_flop / args.steps / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4),
-                               # the HBM-bound kernels of the step (LayerNorm with the fused residual add / splice; attention, dQ + dK/dV kernels
-                               # together): algorithmic bytes / HIP-event time of the vision tower's launches, against the 8 TB/s spec
-                               "hbm_kernels": hbm}
+                               # the HBM-bound kernels of the step (LayerNorm with the fused residual add / splice; attention): algorithmic bytes /
+                               # HIP-event time of the vision tower's launches, against the 8 TB/s spec; measured in hbm_kernels_steps extra
+                               # steps right after the timed region (event pairs on every launch would slow the timed steps by 3 %)
+                               "hbm_kernels": hbm, "hbm_kernels_steps": hbm_steps}
         if parity_ms is not None:
             out["parity_mode_ms_per_step"] = round(parity_ms, 3)
             out["parity_mode"] = "dtype fp16: fp16 MFMA operands, fp32 residual / update / gradient streams, split text-tower operands (logits within 1e-3 of the reference: tests/test_model_gpu.py)"

@@ -135,6 +135,9 @@ int mudpt_model_set(mudpt_model* m, const char* name, int32_t value);
 /* Measurement hook (bench.py): bracket every MFMA GEMM launch of the path with HIP events on its launch stream.
  * mudpt_profile_read synchronises and returns the summed duration, the summed algorithmic FLOPs (2 M N K) and
  * the number of launches since the last enable / read. */
+/* enable: 0 = off; 1 = the persistent MFMA GEMM launches only (class 0 below); otherwise a bit mask of the classes of
+ * mudpt_profile_read_classes (31 = all).  An event pair costs ~5 us of queue time per bracketed launch (measured: 157 pairs = 0.8 ms
+ * per step), so the timed region of bench.py brackets the dominant kernel only and the other classes are measured in a separate pass. */
 int mudpt_profile_enable(mudpt_model* m, int32_t enable);
 int mudpt_profile_read(mudpt_model* m, double* gemm_ms, double* gemm_flop, int64_t* launches);
 /* The same per kernel class (arrays of MUDPT_PROF_CLASSES entries): 0 the persistent MFMA GEMM (work = algorithmic FLOPs), 1 / 2

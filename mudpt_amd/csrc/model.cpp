@@ -163,6 +163,7 @@ struct mudpt_model {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork_b = nullptr, ev_join_b = nullptr;
     // optional HIP-event timing of the big vision-tower launches (bench.py's roofline legs), by kernel class
     bool prof = false;
+    int prof_mask = 0;  // bit c: launches of class c are bracketed (an event pair costs ~5 us of queue time per launch)
     std::vector<hipEvent_t> ev;  // pairs
     size_t ev_used = 0;
     struct ProfRec { int cls; double work; };
@@ -174,7 +175,7 @@ enum ProfClass : int { PC_GEMM = 0, PC_LN_FWD = 1, PC_LN_BWD = 2, PC_ATTN_FWD = 
 // Next event pair for a bracketed launch of class cls (nullptr-filled when profiling is off).
 static int prof_next(mudpt_model* m, int cls, double work, LaunchProf* out) {
     *out = LaunchProf();
-    if (!m->prof) return MUDPT_OK;
+    if (!m->prof || !(m->prof_mask & (1 << cls))) return MUDPT_OK;
     if (m->ev_used + 2 > m->ev.size()) {
         for (int i = 0; i < 512; ++i) {
             hipEvent_t e;
@@ -1180,6 +1181,7 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
 extern "C" int mudpt_profile_enable(mudpt_model* m, int32_t enable) {
     ARG_CHECK(m, "profile_enable: null model");
     m->prof = enable != 0;
+    m->prof_mask = enable == 1 ? 1 : enable;  // 1 = the dominant kernel only (class 0); otherwise a bit mask of MUDPT_PROF_CLASSES classes
     m->ev_used = 0;
     m->ev_rec.clear();
     m->exec_flop = 0;

@@ -203,7 +203,8 @@ class CustomCLIP(nn.Module):
         capi.check(self.lib.mudpt_sgd_step(self._h, lr, momentum, weight_decay, dampening, int(nesterov), self._stream()), "sgd_step")
         self._text_version = None  # the library wrote the parameters behind torch's version counter
 
-    def profile(self, enable: bool):
+    def profile(self, enable):
+        """False / 0: off; True / 1: bracket the persistent GEMM launches only; an int > 1: bit mask of PROF_CLASSES (31 = all)."""
         capi.check(self.lib.mudpt_profile_enable(self._h, int(enable)), "profile_enable")
 
     def profile_read(self):
