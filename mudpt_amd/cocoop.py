@@ -70,6 +70,9 @@ class CoCoOp(TrainerX):
         self.scaler = None  # loss scaling lives inside the library
         if parallel.world_size() > 1:  # the reference's nn.DataParallel (:244-247) becomes one process per GPU
             parallel.broadcast_params(self.model.flat_params)
+        from .prefetch import DevicePrefetcher  # the next batch's host -> device copy overlaps the current step
+        if getattr(self, "train_loader_x", None) is not None and not isinstance(self.train_loader_x, DevicePrefetcher):
+            self.train_loader_x = DevicePrefetcher(self.train_loader_x, device=f"cuda:{local}")
 
     def forward_backward(self, batch):
         # loss = model(image, label) (cross-entropy inside forward, :196-197) + backward in one library call
@@ -78,7 +81,8 @@ class CoCoOp(TrainerX):
     def parse_batch_train(self, batch):
         input = batch["img"]
         label = batch["label"]
-        input, label = parallel.shard_batch(input, label)  # N > 1: this rank's slice, as nn.DataParallel's scatter (:244-247)
+        if not batch.get("_mudpt_sharded", False):  # batches from the DevicePrefetcher are already sliced and on the device
+            input, label = parallel.shard_batch(input, label)  # N > 1: this rank's slice, as nn.DataParallel's scatter (:244-247)
         input = input.to(self.device)
         label = label.to(self.device)
         return input, label

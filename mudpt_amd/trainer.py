@@ -151,6 +151,10 @@ class MuDPT(TrainerX):
         # the reference wraps in nn.DataParallel when device_count > 1 (:230-233); here: one process per GPU
         if parallel.world_size() > 1:
             parallel.broadcast_params(self.model.flat_params)
+        # overlap the next batch's host -> device copy with the current step (the reference copies synchronously at the top of each step)
+        from .prefetch import DevicePrefetcher
+        if getattr(self, "train_loader_x", None) is not None and not isinstance(self.train_loader_x, DevicePrefetcher):
+            self.train_loader_x = DevicePrefetcher(self.train_loader_x, device=f"cuda:{local}")
 
     def forward_backward(self, batch):
         return data_parallel_step(self, batch)
@@ -159,8 +163,10 @@ class MuDPT(TrainerX):
         input = batch["img"]
         label = batch["label"]
         # N > 1: this rank's contiguous slice of the global batch, as nn.DataParallel's scatter (trainers/mudpt.py:230-233); the slice
-        # is taken on the host so only 1/world of the images crosses PCIe
-        input, label = parallel.shard_batch(input, label)
+        # is taken on the host so only 1/world of the images crosses PCIe.  Batches that come through the DevicePrefetcher are already
+        # sliced and on the device (their copy overlapped the previous step): the two .to(device) below are then no-ops.
+        if not batch.get("_mudpt_sharded", False):
+            input, label = parallel.shard_batch(input, label)
         input = input.to(self.device)
         label = label.to(self.device)
         return input, label

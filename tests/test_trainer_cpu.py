@@ -85,3 +85,21 @@ def test_load_pretrained_weights_matches_names_and_shapes(tmp_path):
     before_bias = dst.bias.detach().clone()
     dassl_lite.load_pretrained_weights(dst, str(path))
     assert torch.equal(dst.weight, src.weight) and torch.equal(dst.bias, before_bias)  # wrong-shaped bias is discarded
+
+
+def test_device_prefetcher_is_transparent_without_a_gpu():
+    """On a box without a HIP device the prefetcher passes the loader through: same batches, same order, same length, attributes
+    of the wrapped loader reachable (Dassl reads train_loader_x.dataset / len())."""
+    from mudpt_amd.prefetch import DevicePrefetcher
+
+    class Loader(list):
+        dataset = "the dataset"
+    batches = Loader({"img": torch.full((2, 3, 4, 4), float(i)), "label": torch.tensor([i, i + 1]), "impath": [str(i)]} for i in range(5))
+    pf = DevicePrefetcher(batches, device=None if not torch.cuda.is_available() else "cuda:0")
+    assert len(pf) == 5 and pf.dataset == "the dataset"
+    for epoch in range(2):  # re-iterable, like a DataLoader
+        got = list(pf)
+        assert len(got) == 5
+        for i, b in enumerate(got):
+            assert b["impath"] == [str(i)] and torch.equal(b["img"].cpu(), batches[i]["img"]) and torch.equal(b["label"].cpu(), batches[i]["label"])
+    assert list(DevicePrefetcher(Loader())) == []

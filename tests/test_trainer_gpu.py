@@ -137,3 +137,36 @@ def test_c_abi_allreduce_over_a_one_rank_rccl_communicator():
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
     m.close()
+
+
+def test_prefetched_epoch_equals_the_plain_loop(tmp_path):
+    """build_model wraps train_loader_x in the DevicePrefetcher (next batch's host -> device copy on a side stream during the current
+    step).  An epoch through it gives the same losses, bit for bit, as feeding the raw host batches one by one to a second trainer."""
+    from mudpt_amd import dassl_lite, trainer  # noqa: F401
+    from mudpt_amd.prefetch import DevicePrefetcher
+
+    def make():
+        cfg = dassl_lite.default_cfg()
+        cfg.OUTPUT_DIR = str(tmp_path)
+        cfg.OPTIM.MAX_EPOCH, cfg.OPTIM.WARMUP_EPOCH, cfg.OPTIM.LR = 1, 0, 0.01
+        cfg.DATASET.NUM_TRAIN, cfg.DATASET.NUM_TEST = 20, 4
+        cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.DATALOADER.TEST.BATCH_SIZE = 4, 4
+        cfg.TRAINER.MUDPT.N_CTX, cfg.TRAINER.MUDPT.DEEP_PROMPT_DEPTH = 4, 12
+        return dassl_lite.build_trainer(cfg)
+    a, b = make(), make()
+    assert isinstance(a.train_loader_x, DevicePrefetcher) and len(a.train_loader_x) == 5
+    a.set_model_mode("train")
+    a.num_batches = len(a.train_loader_x)
+    la = []
+    for a.batch_idx, batch in enumerate(a.train_loader_x):
+        assert batch["img"].is_cuda and batch["_mudpt_sharded"]
+        la.append(a.forward_backward(batch)["loss"])
+    b.set_model_mode("train")
+    b.num_batches = 5
+    lb = []
+    for b.batch_idx in range(5):
+        lb.append(b.forward_backward(b.train_loader_x[b.batch_idx])["loss"])  # raw host batch: the synchronous .to(device) path
+    assert la == lb and all(x == x for x in la)
+    assert torch.equal(a.model.flat_params, b.model.flat_params)
+    a.model.close()
+    b.model.close()
