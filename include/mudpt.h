@@ -186,6 +186,10 @@ int mudpt_head(const float* img, const float* txt, const int64_t* labels, float 
  * splice.  src_f32 [B, L, d] or its T copy src_lp (at least one non-NULL); zero_src clears the summed rows afterwards. */
 int mudpt_reduce_rows(int32_t dtype, float* src_f32, void* src_lp, int32_t B, int32_t L, int32_t d, int32_t row0, int32_t n,
                       float* out, int32_t zero_src, int32_t accumulate, float scale, void* stream);
+/* CoCoOp (trainers/cocoop.py:141-146,187-194): dbias[i, :] = scale * sum over image i's C prompts and their n context rows (rows
+ * 1..n of every L-row sequence) of the text-input gradient dx [B * C, L, d] (fp32, or its T copy dx_lp); fixed order: reproducible. */
+int mudpt_cocoop_dbias(int32_t dtype, const float* dx_f32, const void* dx_lp, float* dbias, int32_t B, int32_t C, int32_t L, int32_t d,
+                       int32_t n, float scale, void* stream);
 /* fp32 C[M,N] = alpha * op(A) . op(B) (+ bias[N]) (+ beta * C): the prompt projections (trainers/mudpt.py:127-128, clip/model.py:539). */
 int mudpt_sgemm(int32_t transA, int32_t transB, int32_t M, int32_t N, int32_t K, float alpha, const float* A, int32_t lda,
                 const float* B, int32_t ldb, float beta, float* C, int32_t ldc, const float* bias, void* stream);

@@ -64,6 +64,7 @@ SIGNATURES = {
                                          _vp, _vp, _i32, _i32, _vp]),
     "mudpt_head": (_i32, [_vp, _vp, _vp, _f32, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mudpt_reduce_rows": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _vp]),
+    "mudpt_cocoop_dbias": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "mudpt_sgemm": (_i32, [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _i32, _vp, _i32, _f32, _vp, _i32, _vp, _vp]),
 }
 

@@ -1299,6 +1299,10 @@ extern "C" int mudpt_reduce_rows(int32_t dtype, float* src, void* src_lp, int32_
                                  int32_t zero_src, int32_t accumulate, float scale, void* stream) {
     return launch_reduce_rows(dtype, src, src_lp, B, L, d, row0, n, out, zero_src != 0, accumulate != 0, scale, (hipStream_t)stream);
 }
+extern "C" int mudpt_cocoop_dbias(int32_t dtype, const float* dx_f32, const void* dx_lp, float* dbias, int32_t B, int32_t C, int32_t L, int32_t d, int32_t n,
+                                  float scale, void* stream) {
+    return launch_cocoop_dbias(dtype, dx_f32, dx_lp, dbias, B, C, L, d, n, scale, (hipStream_t)stream);
+}
 extern "C" int mudpt_sgemm(int32_t tA, int32_t tB, int32_t M, int32_t N, int32_t K, float alpha, const float* A, int32_t lda, const float* B, int32_t ldb,
                            float beta, float* C, int32_t ldc, const float* bias, void* stream) {
     return launch_sgemm(tA != 0, tB != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, (hipStream_t)stream);

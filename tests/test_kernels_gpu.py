@@ -282,6 +282,29 @@ def test_reduce_rows(lib, dtype, B, L, d, row0, n):
     assert torch.equal(lp[:, keep.cuda()].cpu(), src.to(tt)[:, keep])  # other rows untouched
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,C,L,d,n", [(64, 11, 9, 512, 4), (3, 100, 20, 512, 4), (2, 5, 7, 128, 2)])
+def test_cocoop_dbias(lib, dtype, B, C, L, d, n):
+    """Gradient of meta_net's per-image context shift (trainers/cocoop.py:141-146): the sum over an image's C prompts and n context rows
+    of the text-input gradient; from the fp32 stream and from its T copy, against a float64 sum, bit for bit run to run."""
+    dt, tt = DT[dtype]
+    g = torch.Generator().manual_seed(B * C + L)
+    dx = torch.randn(B * C, L, d, generator=g)
+    ref = dx.view(B, C, L, d)[:, :, 1:1 + n].double().sum((1, 2))
+    dxc, out = dx.cuda(), torch.empty(B, d, device="cuda")
+    ok(lib, lib.mudpt_cocoop_dbias(dt, P(dxc), None, P(out), B, C, L, d, n, 0.5, None))
+    torch.cuda.synchronize()
+    tol = 4e-6 * (C * n) ** 0.5
+    assert (out.cpu().double() - 0.5 * ref).abs().max().item() <= tol
+    lp = dx.to(tt).cuda()
+    ref_lp = lp.cpu().float().view(B, C, L, d)[:, :, 1:1 + n].double().sum((1, 2))
+    out2, out3 = torch.empty(B, d, device="cuda"), torch.empty(B, d, device="cuda")
+    ok(lib, lib.mudpt_cocoop_dbias(dt, None, P(lp), P(out2), B, C, L, d, n, 1.0, None))
+    ok(lib, lib.mudpt_cocoop_dbias(dt, None, P(lp), P(out3), B, C, L, d, n, 1.0, None))
+    torch.cuda.synchronize()
+    assert (out2.cpu().double() - ref_lp).abs().max().item() <= 2 * tol and torch.equal(out2, out3)
+
+
 @pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(4, 768, 512), (44, 512, 768), (17, 33, 70), (256, 11, 512)])
 def test_sgemm_all_transpose_forms(lib, tA, tB, M, N, K):
