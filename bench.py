@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning knob passed to mudpt_model_set (A/B runs on one box)")
     ap.add_argument("--attn-two-kernels", action="store_true", help="attention backward as the round-1 dQ + dK/dV kernel pair (A/B of the single-sweep kernel)")
+    ap.add_argument("--no-last-single", action="store_true", help="last block through the general attention kernels on all rows (A/B of the single-query path)")
     ap.add_argument("--fp32-streams", action="store_true", help="keep the update / gradient streams in fp32 (A/B of the bf16 streams)")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a captured hipGraph (implies --no-profile)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the short fp16 (parity configuration) timing appended to the bf16 line")
@@ -111,6 +112,8 @@ def main():
         knobs["lp_grad"] = 0
     if args.attn_two_kernels:
         knobs["attn_two_kernels"] = 1
+    if args.no_last_single:
+        knobs["last_single"] = 0
     shape = ModelShape()  # CLIP ViT-B/16, n_ctx 4, depth 12
     if args.arch == "vit_l14_336":
         shape = ModelShape(image_size=336, patch=14, v_width=1024, v_layers=24, v_heads=16, t_width=768, t_layers=12, t_heads=12, embed_dim=768, n_ctx=4, depth=24)

@@ -126,7 +126,8 @@ int mudpt_sgd_reset(mudpt_model* m);
 int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* host_out, size_t capacity, size_t* numel);
 
 /* Per-handle tuning knobs for A/B measurements in one process (tools/gemm_bench.py, tests); nothing is process-global, so two
- * models in one process do not interfere: "gemm_variant"; "attn_two_kernels" (1 = attention backward as two kernels); "cocoop_chunk"
+ * models in one process do not interfere: "gemm_variant"; "last_single" (0 = the last block's attention on all rows instead of the
+ * single-query form); "attn_two_kernels" (1 = attention backward as two kernels); "cocoop_chunk"
  * (cap on the images per CoCoOp text-tower pass; read by the next mudpt_set_class_prompts); "lp_grad" (bf16 mode: 0 keeps the gradient / update streams in fp32);
  * "txt_split" (fp16 mode: 0 = no split operands in the text tower; only before the first mudpt_set_weight); "txt_trim"
  * (0 = run the text tower on all ctx_len positions; read by the next mudpt_set_class_prompts, which must follow). */
@@ -170,6 +171,15 @@ int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, i
  * fused two-sweep pass, bit 2 = the same with two 16-row blocks per wave, bit 4 = force the single sweep (non-causal, L <= 224). */
 int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                         float* delta, void* dqkv, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream);
+/* Single-query attention of a tower's LAST block (only the CLS / EOT row of its output is used, clip/model.py:549, trainers/mudpt.py:154):
+ * one query per sequence -- q_sel [B, H*64], the query of token row sel_rows[b] (= b * L + position) -- against the K / V thirds of the
+ * packed qkv buffer (causal: keys 0 .. position).  Forward: out_sel [B, H*64], lse_sel [B, H].  Backward: dq_sel [B, H*64] and the k, v
+ * thirds of dqkv for EVERY row (zeros behind a causal limit); the q third of dqkv is not written. */
+int mudpt_attention_fwd_single(int32_t dtype, const void* qkv, const void* q_sel, const int32_t* sel_rows, void* out_sel, float* lse_sel,
+                               int32_t B, int32_t L, int32_t H, int32_t causal, void* stream);
+int mudpt_attention_bwd_single(int32_t dtype, const void* qkv, const void* q_sel, const int32_t* sel_rows, const void* out_sel,
+                               const void* dout_sel, const float* lse_sel, void* dqkv, void* dq_sel, int32_t B, int32_t L, int32_t H,
+                               int32_t causal, void* stream);
 /* LayerNorm forward with everything the transformer block fuses into it (clip/model.py:281-301): v = x[r] + add[r] (fp32 add or T
  * add_lp, either may be NULL; row stride ldadd); rows whose position (r % ov_L) lies in [ov_row0, ov_row0 + ov_n) are REPLACED by
  * ov_rows[(r % ov_L) - ov_row0] (the deep-prompt splice); v is written to xout (fp32, may be NULL) and normalised into out (T or fp32). */

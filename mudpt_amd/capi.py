@@ -60,6 +60,8 @@ SIGNATURES = {
     "mudpt_attention_padded_len": (_i32, [_i32]),
     "mudpt_attention_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mudpt_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mudpt_attention_fwd_single": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mudpt_attention_bwd_single": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mudpt_layernorm_fwd_fused": (_i32, [_i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
                                          _vp, _vp, _i32, _i32, _vp]),
     "mudpt_head": (_i32, [_vp, _vp, _vp, _f32, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

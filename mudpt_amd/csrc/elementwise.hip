@@ -112,6 +112,30 @@ int launch_scatter_rows(const void* src, size_t src_stride, const int* rows, voi
     return MUDPT_OK;
 }
 
+// ---- add_rows: dst[rows[r]] += src[r] in T (the single query's share of the last block's input gradient)
+template <typename T>
+__global__ __launch_bounds__(128) void add_rows_kernel(const typename T::elem* __restrict__ src, const int* __restrict__ rows, typename T::elem* __restrict__ dst, int d) {
+    using vec8 = typename T::vec8;
+    const int r = blockIdx.x;
+    const vec8* in = (const vec8*)(src + (size_t)r * d);
+    vec8* out = (vec8*)(dst + (size_t)rows[r] * d);
+    for (int k = threadIdx.x; k < d / 8; k += blockDim.x) {
+        vec8 a = out[k];
+        const vec8 b = in[k];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (typename T::elem)((float)a[i] + (float)b[i]);
+        out[k] = a;
+    }
+}
+int launch_add_rows(int dtype, const void* src, const int* rows, void* dst, int nrows, int d, hipStream_t s) {
+    ARG_CHECK(src && rows && dst && nrows > 0 && d > 0 && d % 8 == 0, "add_rows: bad arguments");
+    if (dtype == DT_BF16) hipLaunchKernelGGL(add_rows_kernel<BF16>, dim3(nrows), dim3(128), 0, s, (const __bf16*)src, rows, (__bf16*)dst, d);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(add_rows_kernel<F16>, dim3(nrows), dim3(128), 0, s, (const _Float16*)src, rows, (_Float16*)dst, d);
+    else { set_error("add_rows: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
 // ---- reduce_rows: out[i, c] (+)= sum_b src[b, row0 + i, c] (b ascending: bitwise reproducible); optional zeroing
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(float* __restrict__ src, typename T::elem* __restrict__ src_lp, int B, int L, int d,

@@ -99,6 +99,12 @@ struct AttnArgs {
     bool two_kernels = false;   // bwd: the dQ kernel + dK/dV kernel pair instead of the fused single pass (A/B runs, tests)
     int B = 0, L = 0, H = 0; bool causal = false;
 };
+// Single-query forms for the last block (attention_single.hip): ONE query row per sequence (token row a.sel_rows[b]) against all keys
+// (causal: the first pos + 1).  q_sel / dout_sel / dq_sel are compact [B, H*64]; out_sel has row stride ld_out (optional low half out_lo);
+// the backward writes the k and v thirds of a.dqkv for EVERY row (zeros behind a causal limit) and leaves its q third untouched.
+int launch_attn_fwd_single(int dtype, const AttnArgs& a, const void* q_sel, void* out_sel, void* out_lo, int ld_out, float* lse_sel, hipStream_t s);
+int launch_attn_bwd_single(int dtype, const AttnArgs& a, const void* q_sel, const void* out_sel, int ld_out, const void* dout_sel, const float* lse_sel,
+                           void* dq_sel, hipStream_t s);
 int attn_padded_len(int L);
 int launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);
 int launch_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);  // prof spans both kernels
@@ -113,6 +119,8 @@ int launch_set_rows(float* x, int B, int L, int d, int row0, int n, const float*
 // dst[r] = src[rows[r]] (gather) / dst[rows[r]] = src[r] (scatter): whole rows of row_bytes (multiple of 16), strides in bytes.
 int launch_gather_rows(const void* src, size_t src_stride, const int* rows, void* dst, size_t dst_stride, int nrows, int row_bytes, hipStream_t s);
 int launch_scatter_rows(const void* src, size_t src_stride, const int* rows, void* dst, size_t dst_stride, int nrows, int row_bytes, hipStream_t s);
+// dst[rows[r], :] += src[r, :] for nrows rows of d elements of T (fp32 add, one rounding); rows must be distinct
+int launch_add_rows(int dtype, const void* src, const int* rows, void* dst, int nrows, int d, hipStream_t s);
 // out[i, :] = sum_b src[b, row0 + i, :] in fixed order (deterministic); optionally zero the source rows
 // (fp32 and its T copy) afterwards: backward of the splice.  accumulate: out += instead of =.
 // scale multiplies the sum (undoes the static loss scale of the backward pass).

@@ -93,6 +93,9 @@ struct Tower {
     float *xin_sel = nullptr, *xmid_sel = nullptr, *xout_sel = nullptr;  // fp32 [S, d]
     void *attn_sel = nullptr, *h_sel = nullptr, *u_sel = nullptr, *g_sel = nullptr, *dattn_sel = nullptr;  // T
     float* dsel = nullptr; void* dsel_lp = nullptr;  // gradient of the residual stream on the selected rows (fp32 / T)
+    // single-query attention of the last block (attention_single.hip): the one query per sequence, its gradient, its log-sum-exp
+    void *q_sel = nullptr, *dq_sel = nullptr, *dqx_sel = nullptr;  // T [S, d]
+    float* lse_sel = nullptr;                                       // [S, heads]
     // Head of the backward pass: block 0's input gradient is only needed on the n_ctx prompt rows of every sequence (the
     // other rows of the tower input have no trainable ancestor), so its in_proj dX GEMM and ln_1 backward run on those rows.
     const int* head_rows = nullptr;  // [nseq * n_ctx] token rows of the prompt tokens
@@ -153,6 +156,7 @@ struct mudpt_model {
     int gemm_variant = 0;
     bool txt_trim = true;  // run the text tower on positions 0..max(eot) only (read by mudpt_set_class_prompts)
     bool attn_fused_w1 = false;
+    bool last_single = true;  // knob: single-query attention in the last block (0 = the general kernels on all rows)
     bool attn_two_kernels = false;  // knob: attention backward as the dQ + dK/dV kernel pair instead of the fused single pass
     int cocoop_chunk = 0;  // knob: cap on the images per text-tower pass (0 = as many as the memory budget allows)
     int txt_chunk = 1;     // CoCoOp: images per text-tower pass, set by mudpt_set_class_prompts
@@ -338,6 +342,7 @@ static int alloc_tower_acts(mudpt_model* m, Tower& t, int L, int max_seq) {
     ALLOC_T(t.xin_sel, S * d * 4); ALLOC_T(t.xmid_sel, S * d * 4); ALLOC_T(t.xout_sel, S * d * 4);
     ALLOC_T(t.attn_sel, S * d * 2 * sp); ALLOC_T(t.h_sel, S * d * 2 * sp); ALLOC_T(t.u_sel, S * 4 * d * 2); ALLOC_T(t.g_sel, S * 4 * d * 2 * sp); ALLOC_T(t.dattn_sel, S * d * 2);
     ALLOC_T(t.dsel, S * d * 4); ALLOC_T(t.dsel_lp, S * d * 2);
+    ALLOC_T(t.q_sel, S * d * 2); ALLOC_T(t.dq_sel, S * d * 2); ALLOC_T(t.dqx_sel, S * d * 2); ALLOC_T(t.lse_sel, S * heads * 4);
     t.head_n = m->cfg.n_ctx;
     ALLOC_T(t.hd_dqkv, S * t.head_n * 3 * d * 2); ALLOC_T(t.hd_h, S * t.head_n * d * 2);
 #undef ALLOC_T
@@ -685,13 +690,13 @@ static int ready(mudpt_model* m, int B, bool need_grads) {
 
 // Forward of the last block after its attention, on the one used row of every sequence (Tower::tail_rows): gathers the
 // rows, then out_proj (+ residual in the small GEMM's epilogue), ln_2, c_fc + QuickGELU, c_proj (+ residual) -> t.xout_sel.
-static int block_fwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
+static int block_fwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s, bool attn_sel_ready = false) {
     const int i = t.layers - 1, S = nseq, d = t.d, dt = m->dtype;
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
     const int sp = t.split ? 2 : 1;  // [hi | lo] operands: rows of sp * d (sp * 4 d) elements, K doubled, B = [W | W]
     const size_t esz = 2;
-    TRY(launch_gather_rows(a.attn, (size_t)sp * d * esz, t.tail_rows, t.attn_sel, (size_t)sp * d * esz, S, sp * d * (int)esz, s));
+    if (!attn_sel_ready) TRY(launch_gather_rows(a.attn, (size_t)sp * d * esz, t.tail_rows, t.attn_sel, (size_t)sp * d * esz, S, sp * d * (int)esz, s));
     TRY(launch_gather_rows(a.x_in, (size_t)d * 4, t.tail_rows, t.xin_sel, (size_t)d * 4, S, d * 4, s));
     GemmArgs o; o.A = t.attn_sel; o.lda = sp * d; o.B = t.split ? w.w_out2 : w.w_out; o.ldb = sp * d; o.M = S; o.N = d; o.K = sp * d; o.bias = w.b_out;
     o.out0 = t.xmid_sel; o.ldo0 = d; o.aux = t.xin_sel; o.ldaux = d;
@@ -731,6 +736,22 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
         if (splice) { l1.ov_rows = splice; l1.ov_row0 = t.prompt_row0; l1.ov_n = n; l1.ov_L = t.L; }
     }
     TRY(ln_fwd_call(m, t, l1, s));
+    if (i + 1 == t.layers && m->last_single && t.tail_rows) {
+        // Last block: only ONE query per sequence is ever used (CLS / EOT row).  K and V for every row (the k, v thirds of in_proj: rows
+        // d .. 3d of its weight, written into the k, v thirds of the packed qkv buffer), q for the selected rows only, single-query attention
+        // straight into the compact attn_sel the tail works on.
+        const char* wkv = (const char*)(t.split ? w.w_in2 : w.w_in) + (size_t)d * sp * d * esz;
+        GemmArgs kv; kv.A = t.h; kv.lda = sp * d; kv.B = wkv; kv.ldb = sp * d; kv.M = M; kv.N = 2 * d; kv.K = sp * d; kv.bias = w.b_in + d;
+        kv.out0 = (char*)a.qkv + (size_t)d * esz; kv.ldo0 = 3 * d;
+        TRY(gemm_call(m, EPI_STORE, kv, s));
+        TRY(launch_gather_rows(t.h, (size_t)sp * d * esz, t.tail_rows, t.h_sel, (size_t)sp * d * esz, nseq, sp * d * (int)esz, s));
+        GemmArgs qs; qs.A = t.h_sel; qs.lda = sp * d; qs.B = t.split ? w.w_in2 : w.w_in; qs.ldb = sp * d; qs.M = nseq; qs.N = d; qs.K = sp * d; qs.bias = w.b_in;
+        qs.out0 = t.q_sel; qs.ldo0 = d;
+        TRY(gemm_call(m, EPI_STORE, qs, s));
+        AttnArgs at; at.qkv = a.qkv; at.sel_rows = t.tail_rows; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
+        TRY(launch_attn_fwd_single(dt, at, t.q_sel, t.attn_sel, t.split ? (char*)t.attn_sel + (size_t)d * esz : nullptr, sp * d, t.lse_sel, s));
+        return block_fwd_tail(m, t, nseq, s, true);
+    }
     GemmArgs q; q.A = t.h; q.lda = sp * d; q.B = t.split ? w.w_in2 : w.w_in; q.ldb = sp * d; q.M = M; q.N = 3 * d; q.K = sp * d; q.bias = w.b_in; q.out0 = a.qkv; q.ldo0 = 3 * d;
     TRY(gemm_call(m, EPI_STORE, q, s));
     AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
@@ -769,6 +790,18 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     TRY(launch_ln_bwd(dt, b2, s));  // t.dsel(_lp) = gradient w.r.t. x_mid on the selected rows
     GemmArgs g3; g3.A = t.dsel_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = S; g3.N = d; g3.K = d; g3.out0 = t.dattn_sel; g3.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g3, s));
+    if (m->last_single) {
+        // single-query attention backward: dK, dV of every row (k, v thirds of t.dqkv) and dq of the one query per sequence
+        AttnArgs at; at.qkv = a.qkv; at.sel_rows = t.tail_rows; at.dqkv = t.dqkv; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
+        TRY(launch_attn_bwd_single(dt, at, t.q_sel, t.attn_sel, (t.split ? 2 : 1) * d, t.dattn_sel, t.lse_sel, t.dq_sel, s));
+        // d(ln_1 output) = dK, dV rows . W_kv  (K range d .. 3d of the transposed in_proj weight)  +  on the selected rows  dq . W_q
+        GemmArgs g4; g4.A = (char*)t.dqkv + (size_t)d * esz; g4.lda = 3 * d; g4.B = (char*)w.w_in_t + (size_t)d * esz; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 2 * d;
+        g4.out0 = t.h; g4.ldo0 = d;
+        TRY(gemm_call(m, EPI_STORE, g4, s));
+        GemmArgs g5; g5.A = t.dq_sel; g5.lda = d; g5.B = w.w_in_t; g5.ldb = 3 * d; g5.M = S; g5.N = d; g5.K = d; g5.out0 = t.dqx_sel; g5.ldo0 = d;
+        TRY(gemm_call(m, EPI_STORE, g5, s));
+        TRY(launch_add_rows(dt, t.dqx_sel, t.tail_rows, t.h, S, d, s));
+    } else {
     // attention backward over all keys: d(attention output) is zero except on the selected query rows
     HIP_TRY(hipMemsetAsync(t.dattn, 0, (size_t)M * d * esz, s));
     TRY(launch_scatter_rows(t.dattn_sel, (size_t)d * esz, t.tail_rows, t.dattn, (size_t)d * esz, S, d * (int)esz, s));
@@ -778,6 +811,7 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     TRY(attn_call(m, t, at, true, s));
     GemmArgs g4; g4.A = t.dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 3 * d; g4.out0 = t.h; g4.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g4, s));
+    }
     // the residual path into ln_1's input: d(x_mid), zero except on the selected rows
     HIP_TRY(hipMemsetAsync(t.dx_lp, 0, (size_t)M * d * esz, s));
     TRY(launch_scatter_rows(t.dsel_lp, (size_t)d * esz, t.tail_rows, t.dx_lp, (size_t)d * esz, S, d * (int)esz, s));
@@ -1168,6 +1202,7 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
     if (!strcmp(name, "txt_trim")) { m->txt_trim = value != 0; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
     if (!strcmp(name, "attn_two_kernels")) { m->attn_two_kernels = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "attn_fused_w1")) { m->attn_fused_w1 = value != 0; return MUDPT_OK; }
+    if (!strcmp(name, "last_single")) { m->last_single = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "cocoop_chunk")) { m->cocoop_chunk = value; m->prompts_set = false; return MUDPT_OK; }  // likewise
     if (!strcmp(name, "txt_split")) {  // the [W | W] copies are made while the weights are ingested: decide before the first mudpt_set_weight
         if (m->any_weight_set) { set_error("model_set: txt_split must be set before the first mudpt_set_weight"); return MUDPT_ERR_STATE; }
@@ -1306,6 +1341,16 @@ extern "C" int mudpt_cocoop_dbias(int32_t dtype, const float* dx_f32, const void
 extern "C" int mudpt_sgemm(int32_t tA, int32_t tB, int32_t M, int32_t N, int32_t K, float alpha, const float* A, int32_t lda, const float* B, int32_t ldb,
                            float beta, float* C, int32_t ldc, const float* bias, void* stream) {
     return launch_sgemm(tA != 0, tB != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, (hipStream_t)stream);
+}
+extern "C" int mudpt_attention_fwd_single(int32_t dtype, const void* qkv, const void* q_sel, const int32_t* sel_rows, void* out_sel, float* lse_sel, int32_t B, int32_t L,
+                                          int32_t H, int32_t causal, void* stream) {
+    AttnArgs a; a.qkv = qkv; a.sel_rows = sel_rows; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;
+    return launch_attn_fwd_single(dtype, a, q_sel, out_sel, nullptr, H * 64, lse_sel, (hipStream_t)stream);
+}
+extern "C" int mudpt_attention_bwd_single(int32_t dtype, const void* qkv, const void* q_sel, const int32_t* sel_rows, const void* out_sel, const void* dout_sel,
+                                          const float* lse_sel, void* dqkv, void* dq_sel, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream) {
+    AttnArgs a; a.qkv = qkv; a.sel_rows = sel_rows; a.dqkv = dqkv; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;
+    return launch_attn_bwd_single(dtype, a, q_sel, out_sel, H * 64, dout_sel, lse_sel, dq_sel, (hipStream_t)stream);
 }
 extern "C" int mudpt_attention_padded_len(int32_t L) { return attn_padded_len(L); }
 extern "C" int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream) {

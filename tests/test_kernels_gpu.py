@@ -411,6 +411,51 @@ def test_attention_fwd_bwd(lib, dtype, B, L, H, causal):
         assert torch.equal(twice, other), form
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,L,H,causal", [(5, 201, 12, False), (11, 26, 8, True), (3, 581, 4, False), (4, 77, 2, True), (2, 7, 1, False)])
+def test_attention_single_query(lib, dtype, B, L, H, causal):
+    """The last block's single-query attention (one query per sequence: CLS row 0 for the vision tower, a different EOT position per
+    sequence under the causal mask for the text tower) against the oracle's full attention restricted to that row: output, log-sum-exp,
+    dq, and the dK / dV rows of EVERY key (zeros behind the causal limit); bit for bit run to run."""
+    dt, tt = DT[dtype]
+    g = torch.Generator().manual_seed(B * 100 + L)
+    qkv = torch.randn(B, L, 3 * H * 64, generator=g).to(tt)
+    pos = torch.randint(1, L, (B,), generator=g) if causal else torch.zeros(B, dtype=torch.long)
+    sel = (torch.arange(B) * L + pos).to(torch.int32)
+    dsel = torch.randn(B, H * 64, generator=g).to(tt)
+    q32 = qkv.float().requires_grad_(True)
+    ref = O.attention(q32, H, O.causal_mask(L) if causal else None)      # [B, L, H*64]
+    ref_sel = ref[torch.arange(B), pos]
+    dout = torch.zeros(B, L, H * 64)
+    dout[torch.arange(B), pos] = dsel.float()
+    (dref,) = torch.autograd.grad(ref, q32, dout)
+    qc, sc = qkv.cuda(), sel.cuda()
+    q_sel = qkv[torch.arange(B), pos, :H * 64].contiguous().cuda()
+    out_sel, lse_sel = torch.empty(B, H * 64, device="cuda", dtype=tt), torch.empty(B, H, device="cuda")
+    ok(lib, lib.mudpt_attention_fwd_single(dt, P(qc), P(q_sel), P(sc), P(out_sel), P(lse_sel), B, L, H, int(causal), None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out_sel.cpu().float(), ref_sel.detach(), atol=6 * EPS[dtype], rtol=6 * EPS[dtype])
+    qh, kh = q32.detach()[..., :H * 64].view(B, L, H, 64), q32.detach()[..., H * 64:2 * H * 64].view(B, L, H, 64)
+    sco = torch.einsum("bhd,blhd->bhl", qh[torch.arange(B), pos], kh) / 8
+    if causal:
+        sco = sco.masked_fill(torch.arange(L).view(1, 1, L) > pos.view(B, 1, 1), float("-inf"))
+    torch.testing.assert_close(lse_sel.cpu(), torch.logsumexp(sco, dim=-1), atol=1e-3, rtol=1e-4)
+    dqkv = torch.full((B, L, 3 * H * 64), 7.0, device="cuda", dtype=tt)  # the q third must stay untouched
+    dq_sel = torch.empty(B, H * 64, device="cuda", dtype=tt)
+    dc = dsel.cuda()
+    ok(lib, lib.mudpt_attention_bwd_single(dt, P(qc), P(q_sel), P(sc), P(out_sel), P(dc), P(lse_sel), P(dqkv), P(dq_sel), B, L, H, int(causal), None))
+    torch.cuda.synchronize()
+    scale = dref.abs().max().item()
+    tol = dict(atol=12 * EPS[dtype] * scale, rtol=8 * EPS[dtype])
+    torch.testing.assert_close(dq_sel.cpu().float(), dref[torch.arange(B), pos, :H * 64], **tol)
+    torch.testing.assert_close(dqkv.cpu().float()[..., H * 64:], dref[..., H * 64:], **tol)
+    assert (dqkv[..., :H * 64] == 7.0).all()
+    again, dq2 = torch.zeros_like(dqkv), torch.empty_like(dq_sel)
+    ok(lib, lib.mudpt_attention_bwd_single(dt, P(qc), P(q_sel), P(sc), P(out_sel), P(dc), P(lse_sel), P(again), P(dq2), B, L, H, int(causal), None))
+    torch.cuda.synchronize()
+    assert torch.equal(again[..., H * 64:], dqkv[..., H * 64:]) and torch.equal(dq2, dq_sel)
+
+
 def test_attention_softmax_extremes(lib):
     """Large score spread: one key dominates a row (exp underflow for the rest) -- no NaN, matches the oracle."""
     B, L, H = 1, 201, 1

@@ -209,3 +209,23 @@ def test_text_tower_trim_changes_nothing():
     for k, g in out[0][2].items():
         scale = g.pow(2).mean().sqrt().item()
         torch.testing.assert_close(out[1][2][k], g, atol=1e-4 * scale + 1e-12, rtol=0, msg=k)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_last_block_single_query_path_equals_the_general_kernels(dtype):
+    """The last block runs single-query attention (one CLS / EOT query per sequence, K / V projections only, dX GEMM over the k, v
+    thirds + the selected rows' dq share).  Knob last_single = 0 runs the general kernels on all rows instead: same logits and
+    gradients up to T-precision rounding of differently ordered sums."""
+    case = GoldenCase("mudpt_vitb16_b4")
+    out = {}
+    for single in (1, 0):
+        m = build(case, dtype, knobs={"last_single": single})
+        loss, logits = m.forward_backward(case.images, case.labels, return_logits=True)
+        torch.cuda.synchronize()
+        out[single] = (logits.cpu(), loss.item(), {k: g.detach().cpu().clone() for k, g in m.grads().items()})
+        m.close()
+    tol = {"fp16": 2e-4, "bf16": 6e-3}[dtype]
+    assert (out[1][0] - out[0][0]).abs().max().item() <= tol
+    for k, g in out[0][2].items():
+        rms = g.pow(2).mean().sqrt().item()
+        assert (out[1][2][k] - g).pow(2).mean().sqrt().item() <= {"fp16": 5e-3, "bf16": 6e-2}[dtype] * rms + 1e-12, k
