@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between the ranks of a node needs it on this driver
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -80,6 +82,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--prof-stride", type=int, default=4, help="bracket every n-th persistent-GEMM launch with HIP events (1 = all; an event pair "
+                    "costs ~4 us of queue time, and the launch counter runs across steps so every launch site is sampled equally often)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning knob passed to mudpt_model_set (A/B runs on one box)")
     ap.add_argument("--attn-two-kernels", action="store_true", help="attention backward as the round-1 dQ + dK/dV kernel pair (A/B of the single-sweep kernel)")
     ap.add_argument("--no-last-single", action="store_true", help="last block through the general attention kernels on all rows (A/B of the single-query path)")
@@ -156,7 +160,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    stride = max(1, args.prof_stride)
     if not args.no_profile:
+        model.set_knob("prof_stride", stride)
         model.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -164,8 +170,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     classes, exec_flop = model.profile_read_classes() if not args.no_profile else ({}, 0.0)
-    gemm_ms, gemm_flop, gemm_n = classes.get("gemm_pp", (0.0, 0.0, 0))
+    gemm_ms, gemm_flop, gemm_n = classes.get("gemm_pp", (0.0, 0.0, 0))  # of the SAMPLED launches (every stride-th)
     model.profile(False)
+    model.set_knob("prof_stride", 1)
     # The HBM-bound kernel classes (LayerNorm, attention) are measured in their own short pass AFTER the timed region: an event pair costs
     # ~5 us of queue time per bracketed launch, and bracketing all 157 big launches of a step slowed the timed steps by 0.8 ms (3 %).
     hbm_steps = 0
@@ -252,11 +259,13 @@ def main():
                                "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": round(pmc["traffic_bytes_per_launch"]) if pmc else None,
                                "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE of separate --pmc passes, profiles/r02_bytes_per_step.md)",
                                "flop_per_launch": round(gemm_flop / gemm_n),
-                               "kernel": f"gemm_pp_kernel (persistent MFMA GEMM: the {gemm_n // args.steps} big vision-tower GEMM launches per step; "
-                                         "achieved = executed 2MNK / event time of those launches)",
-                               "executed_gemm_tflop_per_step": round(gemm_flop / args.steps / 1e12, 3),
-                               "launches_per_step": gemm_n // args.steps, "avg_launch_us": round(gemm_ms * 1e3 / gemm_n, 2),
-                               "gemm_share_of_step": round(gemm_ms / (elapsed * 1e3), 4),
+                               "kernel": f"gemm_pp_kernel (persistent MFMA GEMM: the {round(gemm_n * stride / args.steps)} big vision-tower GEMM launches per step; "
+                                         f"achieved = executed 2MNK / HIP-event time of the bracketed launches: every {stride}-th launch, counted across "
+                                         "steps, so each launch site is sampled equally often)",
+                               "executed_gemm_tflop_per_step": round(gemm_flop * stride / args.steps / 1e12, 3),
+                               "launches_per_step": round(gemm_n * stride / args.steps), "sampled_launches": gemm_n, "sample_stride": stride,
+                               "avg_launch_us": round(gemm_ms * 1e3 / gemm_n, 2),
+                               "gemm_share_of_step": round(gemm_ms * stride / (elapsed * 1e3), 4),
                                # whole step.  step_* use the reference's ALGORITHMIC FLOPs (73.5 GFLOP per image): the library skips
                                # rows nothing uses (the last block's tail, block 0's backward, text positions behind the last EOT), so
                                # that figure credits eliminated work and is NOT a utilisation.  executed_* counts what ran on the matrix cores

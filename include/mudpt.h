@@ -129,6 +129,7 @@ int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* hos
  * models in one process do not interfere: "gemm_variant"; "last_single" (0 = the last block's attention on all rows instead of the
  * single-query form); "attn_two_kernels" (1 = attention backward as two kernels); "cocoop_chunk"
  * (cap on the images per CoCoOp text-tower pass; read by the next mudpt_set_class_prompts); "lp_grad" (bf16 mode: 0 keeps the gradient / update streams in fp32);
+ * "prof_stride" (measurement mode brackets every prof_stride-th persistent-GEMM launch, counted across steps);
  * "txt_split" (fp16 mode: 0 = no split operands in the text tower; only before the first mudpt_set_weight); "txt_trim"
  * (0 = run the text tower on all ctx_len positions; read by the next mudpt_set_class_prompts, which must follow). */
 int mudpt_model_set(mudpt_model* m, const char* name, int32_t value);

@@ -168,6 +168,9 @@ struct mudpt_model {
     // optional HIP-event timing of the big vision-tower launches (bench.py's roofline legs), by kernel class
     bool prof = false;
     int prof_mask = 0;  // bit c: launches of class c are bracketed (an event pair costs ~5 us of queue time per launch)
+    int prof_stride = 1;  // knob: every prof_stride-th gemm_pp launch is bracketed (launch counter runs across steps: with a launch
+                          // count per step coprime to the stride, every launch site is sampled equally often over `stride` steps)
+    long pp_seen = 0;
     std::vector<hipEvent_t> ev;  // pairs
     size_t ev_used = 0;
     struct ProfRec { int cls; double work; };
@@ -203,6 +206,7 @@ static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s) 
     o.variant = m->gemm_variant;
     if (m->prof) m->exec_flop += 2.0 * a.M * a.N * a.K;
     if (!m->prof || !gemm_uses_pp(epi, a, o.variant)) return launch_gemm(m->dtype, epi, a, s, o);
+    if (m->prof_stride > 1 && (m->pp_seen++ % m->prof_stride) != 0) return launch_gemm(m->dtype, epi, a, s, o);
     LaunchProf lp;
     if (int rc = prof_next(m, PC_GEMM, 2.0 * a.M * a.N * a.K, &lp)) return rc;
     o.ev_start = lp.start;
@@ -1203,6 +1207,7 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
     if (!strcmp(name, "attn_two_kernels")) { m->attn_two_kernels = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "attn_fused_w1")) { m->attn_fused_w1 = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "last_single")) { m->last_single = value != 0; return MUDPT_OK; }
+    if (!strcmp(name, "prof_stride")) { m->prof_stride = value > 1 ? value : 1; return MUDPT_OK; }
     if (!strcmp(name, "cocoop_chunk")) { m->cocoop_chunk = value; m->prompts_set = false; return MUDPT_OK; }  // likewise
     if (!strcmp(name, "txt_split")) {  // the [W | W] copies are made while the weights are ingested: decide before the first mudpt_set_weight
         if (m->any_weight_set) { set_error("model_set: txt_split must be set before the first mudpt_set_weight"); return MUDPT_ERR_STATE; }
@@ -1220,6 +1225,7 @@ extern "C" int mudpt_profile_enable(mudpt_model* m, int32_t enable) {
     m->ev_used = 0;
     m->ev_rec.clear();
     m->exec_flop = 0;
+    m->pp_seen = 0;
     return MUDPT_OK;
 }
 // Synchronises the device; sums per kernel class over the launches recorded since the last enable / read, then clears the records.
