@@ -12,6 +12,7 @@
  *   mudpt_forward_backward               trainers/mudpt.py:249-251 forward, F.cross_entropy, backward
  *   mudpt_sgd_step                       trainers/mudpt.py:251     model_backward_and_update's optimizer step
  *   mudpt_allreduce_grads                trainers/mudpt.py:230-233 nn.DataParallel's gradient reduce (here: one RCCL all-reduce)
+ *   mudpt_set_class_shard / mudpt_cp_*   trainers/mudpt.py:142-156,178-182 the same step with the class prompts divided over the ranks
  *   mudpt_gemm / _layernorm_* / _attention_*   the ATen ops under clip/model.py:164-175,257-301 (unit parity)
  * With mudpt_config.variant = MUDPT_VARIANT_COCOOP the same entry points run the CoCoOp path (trainers/cocoop.py):
  *   mudpt_create / mudpt_set_weight      trainers/cocoop.py:22-40  load_clip_to_cpu: vanilla CLIP (clip/model.py:443-496 ViT)
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MUDPT_ABI_VERSION 3
+#define MUDPT_ABI_VERSION 4
 
 #define MUDPT_OK 0
 #define MUDPT_ERR_ARG 1   /* bad argument / shape (the reference raises AssertionError, mudpt.py:52,55,190) */
@@ -108,6 +109,29 @@ int mudpt_forward_backward(mudpt_model* m, const float* images_dev, const int64_
  * passes its RCCL communicator (ncclComm_t as void*, created with ncclCommInitRank) here.  In place on the bound bucket, asynchronous
  * on `stream`; RCCL is resolved from the process at first use (no link-time dependency). */
 int mudpt_allreduce_grads(mudpt_model* m, void* nccl_comm, void* stream);
+
+/* Class-parallel text tower: the second axis for many classes (ImageNet, C = 1000).  The reference replicates the text tower over all C
+ * class prompts on every GPU (trainers/mudpt.py:142-156 inside nn.DataParallel, :230-233); here rank r may encode classes [c0, c1) only.
+ * mudpt_set_class_shard comes before mudpt_set_class_prompts (which still receives ALL n_cls prompts on every rank and keeps its own).
+ * A sharded handle refuses mudpt_forward / mudpt_forward_backward; one step is
+ *   mudpt_cp_forward(images)        both towers; rows c0..c1-1 of feat[n_cls, embed] = this rank's text features, other rows zero
+ *   exchange 1                      all-reduce(sum) -- or all-gather -- of feat over the ranks
+ *   mudpt_cp_head(labels, ...)      logits / loss of the LOCAL images against ALL classes; backward -> dfeat[n_cls, embed]
+ *                                   (labels NULL: inference, logits only, no exchange 2 / backward)
+ *   exchange 2                      all-reduce(sum) of dfeat (every rank's images contribute to every class); it may overlap
+ *   mudpt_cp_backward(MUDPT_CP_VISION)   ... the vision tower's backward, which does not read dfeat
+ *   mudpt_cp_backward(MUDPT_CP_TEXT)     text tower backward over the local classes + prompt-learner backward, after exchange 2
+ *   the gradient-bucket all-reduce  as in pure data parallelism (text-side gradients are partial sums over classes)
+ * mudpt_cp_buffers returns the two fp32 device tables (library-owned, numel = n_cls * embed_dim).  Every phase is asynchronous on `stream`;
+ * the caller orders its exchanges on that stream.  An unsharded handle may run the phases too (one rank: no exchange needed). */
+#define MUDPT_CP_VISION 1
+#define MUDPT_CP_TEXT 2
+int mudpt_set_class_shard(mudpt_model* m, int32_t class_begin, int32_t class_end);
+int mudpt_cp_buffers(mudpt_model* m, float** feat_dev, float** dfeat_dev, size_t* numel);
+int mudpt_cp_forward(mudpt_model* m, const float* images_dev, int32_t batch, int32_t flags, void* stream);
+int mudpt_cp_head(mudpt_model* m, const int64_t* labels_dev, int32_t batch, float grad_scale, float* loss_dev, float* logits_dev,
+                  int32_t flags, void* stream);
+int mudpt_cp_backward(mudpt_model* m, int32_t part, void* stream);
 
 /* Static loss scale of the backward pass (default 128): per-sample logit gradients are multiplied by it so the
  * fp16 copies of the token gradients stay normal; the gradients written to the bucket are unscaled again.

@@ -11,7 +11,7 @@ HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "mudpt.h")
 
 BF16, F16 = 0, 1
 VARIANT_MUDPT, VARIANT_COCOOP = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD, EPI_PATCH, EPI_STORE_F32 = range(6)
 
 
@@ -46,6 +46,11 @@ SIGNATURES = {
     "mudpt_sgd_step": (_i32, [_vp, _f32, _f32, _f32, _f32, _i32, _vp]),
     "mudpt_sgd_reset": (_i32, [_vp]),
     "mudpt_allreduce_grads": (_i32, [_vp, _vp, _vp]),
+    "mudpt_set_class_shard": (_i32, [_vp, _i32, _i32]),
+    "mudpt_cp_buffers": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
+    "mudpt_cp_forward": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "mudpt_cp_head": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i32, _vp]),
+    "mudpt_cp_backward": (_i32, [_vp, _i32, _vp]),
     "mudpt_debug_read": (_i32, [_vp, C.c_char_p, _i32, _vp, _sz, C.POINTER(_sz)]),
     "mudpt_set_loss_scale": (_i32, [_vp, _f32]),
     "mudpt_model_set": (_i32, [_vp, C.c_char_p, _i32]),
@@ -106,6 +111,25 @@ def check(rc: int, what: str = ""):
         if rc == 1:
             raise AssertionError(f"mudpt {what}: {msg}")  # the reference asserts on bad cfg (trainers/mudpt.py:52,55,190)
         raise MudptError(f"mudpt {what}: {kind}: {msg}")
+
+
+CP_VISION, CP_TEXT = 1, 2  # mudpt_cp_backward parts
+
+
+class _DeviceMemory:
+    """fp32 device memory the library owns, exposed through the CUDA array interface (no copy, no ownership)."""
+
+    def __init__(self, address: int, numel: int):
+        self.__cuda_array_interface__ = {"shape": (numel,), "typestr": "<f4", "data": (address, False), "version": 2}
+
+
+def device_view(address: int, numel: int, device):
+    """torch view (fp32, flat) of library-owned device memory: the operand of a torch.distributed collective."""
+    import torch
+    t = torch.as_tensor(_DeviceMemory(address, numel), device=device)
+    if t.data_ptr() != address:
+        raise MudptError("device_view: torch copied the buffer instead of aliasing it")
+    return t
 
 
 def ptr(t):

@@ -146,6 +146,12 @@ struct mudpt_model {
     // CoCoOp variant (trainers/cocoop.py): 5 trainables, vanilla vision tower (forward only), B * C text sequences
     bool cocoop = false;
     int nparams = 10;
+    // Class-parallel text tower (second axis): this handle encodes classes [c0, c0 + ct) of the n_cls only; the
+    // [n_cls, e] text-feature table is completed by the caller's exchange between the mudpt_cp_* phases.  Default: all classes.
+    int c0 = 0, ct = 0;
+    bool sharded = false;
+    float cp_unscale = 0.f;  // of the step in flight between mudpt_cp_head and mudpt_cp_backward
+    int cp_B = 0, cp_stage = 0;  // 1 = towers forward done, 2 = head (training) done
     int hid = 0;  // meta_net hidden width = embed_dim / 16 (trainers/cocoop.py:104)
     float *mn_hid = nullptr, *mn_bias = nullptr, *mn_dbias = nullptr, *mn_dhid = nullptr;  // [B, hid], [B, dt], [B, dt], [B, hid]
     float loss_scale = 128.f;  // static, power of two; see mudpt_forward_backward
@@ -385,6 +391,7 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     m->dtype = c->dtype;
     m->lp_grad = (c->dtype == MUDPT_BF16);
     m->cocoop = cocoop;
+    m->ct = c->n_cls;
     if (cocoop) m->cfg.depth = 1;  // no deep prompts
     const int dv = c->v_width, dt = c->t_width, e = c->embed_dim, n = c->n_ctx, D1 = m->cfg.depth - 1, B = c->max_batch, C = c->n_cls;
     const int TS = cocoop ? B * C : C;  // text sequences per step: one per (image, class) pair in CoCoOp (trainers/cocoop.py:187-194)
@@ -581,17 +588,18 @@ extern "C" int mudpt_set_class_prompts(mudpt_model* m, const float* emb, const i
     for (const std::string& k : m->missing)
         if (k == "positional_embedding") { set_error("set_class_prompts: set 'positional_embedding' first"); return MUDPT_ERR_STATE; }
     const mudpt_config& c = m->cfg;
-    const size_t C = c.n_cls, L = c.ctx_len, d = c.t_width;
+    // emb / eot describe ALL n_cls classes on every rank; a class-sharded handle (mudpt_set_class_shard) keeps its own [c0, c0 + C) only
+    const size_t C = (size_t)m->ct, c0 = (size_t)m->c0, L = c.ctx_len, d = c.t_width;
+    for (int cc = 0; cc < c.n_cls; ++cc) ARG_CHECK(eot[cc] >= 0 && eot[cc] < (int)L, "set_class_prompts: eot index %d out of range", eot[cc]);
+    emb += c0 * L * d;
+    eot += c0;
     // The text tower is causal (clip/model.py:407-413 build_attention_mask) and only the EOT row of each prompt is used
     // (trainers/mudpt.py:154): positions behind the last EOT of the class set influence neither a used output nor a gradient,
     // so the tower runs on the first Le = max(eot) + 1 positions of every prompt ("a photo of a <name>." ends at position 7-9
     // of 77).  Row-wise operators and causal attention make the kept rows bit-identical to the full-length run;
     // mudpt_model_set("txt_trim", 0) keeps all ctx_len positions (A/B runs, tests).
     int max_eot = 0;
-    for (size_t cc = 0; cc < C; ++cc) {
-        ARG_CHECK(eot[cc] >= 0 && eot[cc] < (int)L, "set_class_prompts: eot index %d out of range", eot[cc]);
-        max_eot = std::max(max_eot, (int)eot[cc]);
-    }
+    for (size_t cc = 0; cc < C; ++cc) max_eot = std::max(max_eot, (int)eot[cc]);
     const size_t Le = m->txt_trim ? (size_t)std::max(max_eot + 1, c.n_ctx + 2) : L;
     // Sequences per text-tower pass.  MuDPT: the C class prompts.  CoCoOp: every image has its own C prompts (trainers/cocoop.py:187-194
     // loops over the images, C sequences at a time); here a CHUNK of images goes through the tower at once -- as many as fit a
@@ -993,13 +1001,12 @@ static int cocoop_forward_backward(mudpt_model* m, const float* images, const in
     return MUDPT_OK;
 }
 
-static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t s, bool reuse_text = false, bool skip_head = false) {
-    if (m->cocoop) return cocoop_forward(m, images, B, s);
+// ---- the MuDPT step in pieces (the monolithic entry points and the class-parallel phases share them) ------------------------------
+// prompt learner, trainers/mudpt.py:117-130 + clip/model.py:534-539
+static int prompt_learner_forward(mudpt_model* m, hipStream_t s) {
     const mudpt_config& c = m->cfg;
-    const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, C = c.n_cls;
-    const int Lt = m->txt.L;
+    const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1;
     float* Pm = m->params;
-    // -- prompt learner, trainers/mudpt.py:117-130 + clip/model.py:534-539
     TRY(launch_sgemm(false, true, n, dv, dt, 1.f, Pm + m->off[P_CTX], dt, Pm + m->off[P_EW], dt, 0.f, m->shared, dv, Pm + m->off[P_EB], s));
     if (D1 > 0) {
         TRY(launch_sgemm(false, true, D1 * n, dv, dt, 1.f, Pm + m->off[P_DEEP], dt, Pm + m->off[P_DW], dt, 0.f, m->t2v, dv, Pm + m->off[P_DB], s));
@@ -1007,34 +1014,52 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
         TRY(launch_add(m->t2v, Pm + m->off[P_VDEEP], m->vis_deep, (size_t)D1 * n * dv, s));
         TRY(launch_add(m->v2t, Pm + m->off[P_DEEP], m->txt_deep, (size_t)D1 * n * dt, s));
     }
-    // -- text tower, trainers/mudpt.py:142-156: independent of the vision tower once the prompt learner has run, so it
-    // goes to the side stream (enqueued first): its ~200 small launch-latency-bound kernels fill the CUs the big vision
-    // kernels leave idle (tails of the persistent GEMMs, memory-bound LayerNorms) instead of serialising behind them.
-    // With reuse_text (inference with unchanged parameters: the reference recomputes the text tower for every test batch,
-    // trainers/mudpt.py:170-184) the text features of the previous call are kept.
-    hipStream_t s2 = m->s2;
+    return MUDPT_OK;
+}
+
+// text tower, trainers/mudpt.py:142-156, over this handle's classes [c0, c0 + ct): rows c0.. of the [n_cls, e] feature table
+static int text_forward(mudpt_model* m, hipStream_t s2) {
+    const mudpt_config& c = m->cfg;
+    const int dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, Ct = m->ct;
+    const int Lt = m->txt.L;
+    float* Pm = m->params;
+    HIP_TRY(hipMemcpyAsync(m->txt.a[0].x_in, m->emb_pos, (size_t)Ct * Lt * dt * 4, hipMemcpyDeviceToDevice, s2));
+    TRY(launch_set_rows(m->txt.a[0].x_in, Ct, Lt, dt, 1, n, Pm + m->off[P_CTX], m->tpos + dt, s2));
+    for (int i = 0; i < m->txt.layers; ++i) {
+        TRY(block_fwd(m, m->txt, i, Ct, (i >= 1 && i - 1 < D1) ? m->txt_deep + (size_t)(i - 1) * n * dt : nullptr, s2));
+    }
+    LnFwdArgs lf; lf.x = m->txt.xout_sel; lf.ldx = dt; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
+    lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = Ct; lf.d = dt;
+    TRY(launch_ln_fwd(m->dtype, lf, s2));
+    if (m->sharded) HIP_TRY(hipMemsetAsync(m->txt_f, 0, (size_t)c.n_cls * e * 4, s2));  // other ranks' rows: zero, so a sum completes the table
+    TRY(launch_sgemm(false, false, Ct, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f + (size_t)m->c0 * e, e, nullptr, s2));
+    m->text_valid = true;
+    return MUDPT_OK;
+}
+
+// Both towers' forward.  The text tower is independent of the vision tower once the prompt learner has run, so it goes to the side
+// stream (enqueued first): its ~200 small launch-latency-bound kernels fill the CUs the big vision kernels leave idle (tails of the
+// persistent GEMMs, memory-bound LayerNorms) instead of serialising behind them.  With reuse_text (inference with unchanged
+// parameters: the reference recomputes the text tower for every test batch, trainers/mudpt.py:170-184) the text
+// features of the previous call are kept.
+static int towers_forward(mudpt_model* m, const float* images, int B, hipStream_t s, bool reuse_text) {
+    TRY(prompt_learner_forward(m, s));
     if (!reuse_text) {
         HIP_TRY(hipEventRecord(m->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(s2, m->ev_fork, 0));
-        HIP_TRY(hipMemcpyAsync(m->txt.a[0].x_in, m->emb_pos, (size_t)C * Lt * dt * 4, hipMemcpyDeviceToDevice, s2));
-        TRY(launch_set_rows(m->txt.a[0].x_in, C, Lt, dt, 1, n, Pm + m->off[P_CTX], m->tpos + dt, s2));
-        for (int i = 0; i < m->txt.layers; ++i) {
-            TRY(block_fwd(m, m->txt, i, C, (i >= 1 && i - 1 < D1) ? m->txt_deep + (size_t)(i - 1) * n * dt : nullptr, s2));
-        }
-        LnFwdArgs lf; lf.x = m->txt.xout_sel; lf.ldx = dt; lf.gamma = m->ln_fin_g; lf.beta = m->ln_fin_b; lf.out = m->t_ln; lf.ldo = dt;
-        lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = C; lf.d = dt;
-        TRY(launch_ln_fwd(m->dtype, lf, s2));
-        TRY(launch_sgemm(false, false, C, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f, e, nullptr, s2));
-        HIP_TRY(hipEventRecord(m->ev_join, s2));
-        m->text_valid = true;
+        HIP_TRY(hipStreamWaitEvent(m->s2, m->ev_fork, 0));
+        TRY(text_forward(m, m->s2));
+        HIP_TRY(hipEventRecord(m->ev_join, m->s2));
     }
-    // -- vision tower, clip/model.py:526-553
-    TRY(vision_forward(m, images, B, s));
-    // -- cosine logits, trainers/mudpt.py:178-182 (needs both towers)
+    TRY(vision_forward(m, images, B, s));  // clip/model.py:526-553
     if (!reuse_text) HIP_TRY(hipStreamWaitEvent(s, m->ev_join, 0));
-    if (skip_head) return MUDPT_OK;  // the training step runs the fused forward + cross-entropy + backward head itself
+    return MUDPT_OK;
+}
+
+// cosine logits, trainers/mudpt.py:178-182 (needs both towers' features; txt_f must hold all n_cls rows)
+static int head_forward(mudpt_model* m, int B, bool reuse_text, hipStream_t s) {
+    const mudpt_config& c = m->cfg;
     HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.scale = m->scale; h.logits = m->logits; h.img_n = m->img_n; h.txt_n = m->txt_n;
-    h.img_inv = m->img_inv; h.txt_inv = m->txt_inv; h.B = B; h.C = C; h.e = e;
+    h.img_inv = m->img_inv; h.txt_inv = m->txt_inv; h.B = B; h.C = c.n_cls; h.e = c.embed_dim;
     if (head_fused_fits(h, false)) {
         if (reuse_text) h.txt = nullptr;  // the normalised text features of the previous call are still in m->txt_n
         TRY(launch_head_fused_fwd(h, s));
@@ -1044,12 +1069,25 @@ static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t 
     return MUDPT_OK;
 }
 
+static int forward_impl(mudpt_model* m, const float* images, int B, hipStream_t s, bool reuse_text = false, bool skip_head = false) {
+    if (m->cocoop) return cocoop_forward(m, images, B, s);
+    TRY(towers_forward(m, images, B, s, reuse_text));
+    if (skip_head) return MUDPT_OK;  // the training step runs the fused forward + cross-entropy + backward head itself
+    return head_forward(m, B, reuse_text, s);
+}
+
+static int not_sharded(mudpt_model* m, const char* what) {
+    if (m->sharded) { set_error("%s: this handle encodes classes %d..%d of %d only (mudpt_set_class_shard): use the mudpt_cp_* phases", what, m->c0, m->c0 + m->ct - 1, m->cfg.n_cls); return MUDPT_ERR_STATE; }
+    return MUDPT_OK;
+}
+
 extern "C" int mudpt_forward(mudpt_model* m, const float* images, int32_t B, float* logits, void* stream) {
     return mudpt_forward_ex(m, images, B, logits, 0, stream);
 }
 
 extern "C" int mudpt_forward_ex(mudpt_model* m, const float* images, int32_t B, float* logits, int32_t flags, void* stream) {
     TRY(ready(m, B, false));
+    TRY(not_sharded(m, "forward"));
     ARG_CHECK(images && logits, "forward: null argument");
     hipStream_t s = (hipStream_t)stream;
     const bool reuse = (flags & MUDPT_FWD_REUSE_TEXT) != 0 && !m->cocoop;  // CoCoOp's text features depend on the image
@@ -1059,54 +1097,55 @@ extern "C" int mudpt_forward_ex(mudpt_model* m, const float* images, int32_t B, 
     return MUDPT_OK;
 }
 
-extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const int64_t* labels, int32_t B, float grad_scale,
-                                      float* loss, float* logits, void* stream) {
-    TRY(ready(m, B, true));
-    ARG_CHECK(images && labels && loss, "forward_backward: null argument");
-    hipStream_t s = (hipStream_t)stream;
-    if (m->cocoop) return cocoop_forward_backward(m, images, labels, B, grad_scale, loss, logits, s);
+// head of the training step: cross-entropy (mean) + cosine logits backward, trainers/mudpt.py:178-182,250 -> loss, dimg, dtxt (all classes)
+static int head_train(mudpt_model* m, const int64_t* labels, int B, float grad_scale, float* loss, float* logits, hipStream_t s) {
     const mudpt_config& c = m->cfg;
-    const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, C = c.n_cls;
-    const int Lv = m->vis.L, Lt = m->txt.L;
-    float *Pm = m->params, *G = m->grads;
-    HeadArgs hf; hf.B = B; hf.C = C; hf.e = e;
-    const bool fused_head = head_fused_fits(hf, true);
-    TRY(forward_impl(m, images, B, s, false, fused_head));
-    HIP_TRY(hipMemsetAsync(G, 0, m->total * 4, s));
-
-    // -- head: cross-entropy (mean) + cosine logits backward, trainers/mudpt.py:178-182,250
+    const int e = c.embed_dim, C = c.n_cls;
     HeadArgs h; h.img = m->img_f; h.txt = m->txt_f; h.labels = labels; h.scale = m->scale; h.logits = m->logits; h.loss = m->loss; h.dlogits = m->dlogits;
     h.row_loss = m->row_loss; h.dimg = m->dimg; h.dtxt = m->dtxt; h.img_n = m->img_n; h.txt_n = m->txt_n; h.img_inv = m->img_inv; h.txt_inv = m->txt_inv;
     // Static loss scaling: the backward pass runs on per-sample gradients times loss_scale (dlogits = (softmax -
     // onehot) * loss_scale, independent of B and of the number of ranks), so the T copies of the token gradients
     // stay inside fp16's normal range (unscaled they are ~1e-7 at B = 256: flushed).  The four reductions that leave
     // the towers multiply by `unscale`; everything after them is fp32 and linear.
-    const float unscale = grad_scale / ((float)B * m->loss_scale);
+    m->cp_unscale = grad_scale / ((float)B * m->loss_scale);
     h.grad_scale = m->loss_scale * (float)B; h.B = B; h.C = C; h.e = e;
-    if (fused_head) TRY(launch_head_fused_train(h, s)); else TRY(launch_head_bwd(h, s));
+    if (head_fused_fits(h, true)) {
+        TRY(launch_head_fused_train(h, s));
+    } else {
+        TRY(head_forward(m, B, false, s));
+        TRY(launch_head_bwd(h, s));
+    }
     if (logits) HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(loss, m->loss, 4, hipMemcpyDeviceToDevice, s));
+    return MUDPT_OK;
+}
 
-    // -- text tower backward, on the side stream (enqueued first; joins before the prompt-learner backward).  It only
-    // reads dtxt / its own activations and only writes its own buffers, d_txt_deep and the ctx slice of the gradient bucket.
-    hipStream_t s2 = m->s2;
-    HIP_TRY(hipEventRecord(m->ev_fork_b, s));
-    HIP_TRY(hipStreamWaitEvent(s2, m->ev_fork_b, 0));
+// text tower backward over this handle's classes: reads rows c0.. of dtxt and its own activations, writes only its own buffers,
+// d_txt_deep and the ctx slice of the gradient bucket
+static int text_backward(mudpt_model* m, float unscale, hipStream_t s2) {
+    const mudpt_config& c = m->cfg;
+    const int dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, Ct = m->ct;
+    const int Lt = m->txt.L;
+    float* G = m->grads;
     Tower& X = m->txt;
-    TRY(launch_sgemm(false, true, C, dt, e, 1.f, m->dtxt, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s2));
+    TRY(launch_sgemm(false, true, Ct, dt, e, 1.f, m->dtxt + (size_t)m->c0 * e, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s2));
     LnBwdArgs bf; bf.dy = m->dt_ln; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.xout_sel; bf.ldx = dt; bf.mean = m->fin_mean; bf.rstd = m->fin_rstd;
-    bf.gamma = m->ln_fin_g; bf.dx = m->lp_grad ? nullptr : X.dsel; bf.lddx = dt; bf.dx_lp = X.dsel_lp; bf.lddx_lp = dt; bf.rows = C; bf.d = dt;
+    bf.gamma = m->ln_fin_g; bf.dx = m->lp_grad ? nullptr : X.dsel; bf.lddx = dt; bf.dx_lp = X.dsel_lp; bf.lddx_lp = dt; bf.rows = Ct; bf.d = dt;
     TRY(launch_ln_bwd(m->dtype, bf, s2));
     for (int i = X.layers - 1; i >= 0; --i) {
-        if (i == X.layers - 1) TRY(block_bwd_tail(m, X, C, s2)); else TRY(block_bwd(m, X, i, C, s2));
+        if (i == X.layers - 1) TRY(block_bwd_tail(m, X, Ct, s2)); else TRY(block_bwd(m, X, i, Ct, s2));
         if (i >= 1 && i - 1 < D1)
-            TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, X.dx_lp, C, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, unscale, s2));
+            TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, X.dx_lp, Ct, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, unscale, s2));
     }
     // d ctx (text side): rows 1..n of the first block's input, summed over the class prompts
-    TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, m->lp_grad ? X.dx_lp : nullptr, C, Lt, dt, 1, n, G + m->off[P_CTX], false, true, unscale, s2));
-    HIP_TRY(hipEventRecord(m->ev_join_b, s2));
+    TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, m->lp_grad ? X.dx_lp : nullptr, Ct, Lt, dt, 1, n, G + m->off[P_CTX], false, true, unscale, s2));
+    return MUDPT_OK;
+}
 
-    // -- vision tower backward
+static int vision_backward(mudpt_model* m, int B, float unscale, hipStream_t s) {
+    const mudpt_config& c = m->cfg;
+    const int dv = c.v_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1;
+    const int Lv = m->vis.L;
     Tower& V = m->vis;
     TRY(launch_sgemm(false, true, B, dv, e, 1.f, m->dimg, e, m->vproj, e, 0.f, m->df_ln, dv, nullptr, s));
     LnBwdArgs bq; bq.dy = m->df_ln; bq.lddy = dv; bq.dy_f32 = true; bq.x = V.xout_sel; bq.ldx = dv; bq.mean = m->post_mean; bq.rstd = m->post_rstd;
@@ -1122,9 +1161,14 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     bp.gamma = m->ln_pre_g; bp.dx = V.dx; bp.lddx = dv; bp.rows = B * n; bp.d = dv; bp.by_token = true;
     TRY(launch_ln_bwd(m->dtype, bp, s));
     TRY(launch_reduce_rows(m->dtype, V.dx, nullptr, B, Lv, dv, Lv - n, n, m->d_vprompt0, false, false, unscale, s));
+    return MUDPT_OK;
+}
 
-    // -- prompt learner backward (fp32, tiny): needs both towers' prompt gradients
-    HIP_TRY(hipStreamWaitEvent(s, m->ev_join_b, 0));
+// prompt learner backward (fp32, tiny): needs both towers' prompt gradients
+static int prompt_learner_backward(mudpt_model* m, hipStream_t s) {
+    const mudpt_config& c = m->cfg;
+    const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1;
+    float *Pm = m->params, *G = m->grads;
     // visual_ctx and shared = embed_projection(ctx) both receive d_vprompt0 (clip/model.py:534)
     TRY(launch_add(G + m->off[P_VCTX], m->d_vprompt0, G + m->off[P_VCTX], (size_t)n * dv, s));
     TRY(launch_sgemm(true, false, dv, dt, n, 1.f, m->d_vprompt0, dv, Pm + m->off[P_CTX], dt, 1.f, G + m->off[P_EW], dt, nullptr, s));
@@ -1148,6 +1192,92 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
         TRY(launch_sgemm(false, false, R, dv, e, 1.f, m->d_txt_deep, e, Pm + m->off[P_VW], dv, 1.f, G + m->off[P_VDEEP], dv, nullptr, s));
     }
     return MUDPT_OK;
+}
+
+extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const int64_t* labels, int32_t B, float grad_scale,
+                                      float* loss, float* logits, void* stream) {
+    TRY(ready(m, B, true));
+    ARG_CHECK(images && labels && loss, "forward_backward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (m->cocoop) return cocoop_forward_backward(m, images, labels, B, grad_scale, loss, logits, s);
+    TRY(not_sharded(m, "forward_backward"));
+    TRY(towers_forward(m, images, B, s, false));
+    HIP_TRY(hipMemsetAsync(m->grads, 0, m->total * 4, s));
+    TRY(head_train(m, labels, B, grad_scale, loss, logits, s));
+    // text tower backward on the side stream (enqueued first; joins before the prompt-learner backward)
+    HIP_TRY(hipEventRecord(m->ev_fork_b, s));
+    HIP_TRY(hipStreamWaitEvent(m->s2, m->ev_fork_b, 0));
+    TRY(text_backward(m, m->cp_unscale, m->s2));
+    HIP_TRY(hipEventRecord(m->ev_join_b, m->s2));
+    TRY(vision_backward(m, B, m->cp_unscale, s));
+    HIP_TRY(hipStreamWaitEvent(s, m->ev_join_b, 0));
+    return prompt_learner_backward(m, s);
+}
+
+// ---- class-parallel phases (SURVEY 8e second axis; the reference runs all C prompts on every replica, trainers/mudpt.py:142-156,230-233) ----
+// A handle with mudpt_set_class_shard(c0, c1) encodes classes [c0, c1) only.  One step on every rank:
+//   mudpt_cp_forward          both towers; this rank's rows of the [n_cls, e] text-feature table, the other rows zero
+//   <exchange 1>              all-reduce(sum) (or all-gather) of the table  (mudpt_cp_buffers: feat)
+//   mudpt_cp_head             logits, loss and the head's backward over the LOCAL images and ALL classes -> dimg, dfeat [n_cls, e]
+//   <exchange 2>              all-reduce(sum) of dfeat: every rank's images contribute to every class
+//   mudpt_cp_backward         VISION part may be enqueued before exchange 2 completes; TEXT part (local classes + prompt learner) after it
+//   <the usual all-reduce of the gradient bucket>   text-side gradients are partial sums over classes, vision-side ones over images
+extern "C" int mudpt_set_class_shard(mudpt_model* m, int32_t c0, int32_t c1) {
+    ARG_CHECK(m, "set_class_shard: null model");
+    if (m->cocoop) { set_error("set_class_shard: CoCoOp's text features depend on the image; shard the batch instead"); return MUDPT_ERR_ARG; }
+    ARG_CHECK(c0 >= 0 && c1 > c0 && c1 <= m->cfg.n_cls, "set_class_shard: [%d, %d) is not a non-empty range of the %d classes", c0, c1, m->cfg.n_cls);
+    m->c0 = c0; m->ct = c1 - c0;
+    m->sharded = !(c0 == 0 && c1 == m->cfg.n_cls);
+    m->prompts_set = false;  // the text tower is sized and its tables are built by the next mudpt_set_class_prompts
+    m->text_valid = false;
+    m->cp_stage = 0;
+    return MUDPT_OK;
+}
+extern "C" int mudpt_cp_buffers(mudpt_model* m, float** feat, float** dfeat, size_t* numel) {
+    ARG_CHECK(m && !m->cocoop, "cp_buffers: not a MuDPT model");
+    if (feat) *feat = m->txt_f;
+    if (dfeat) *dfeat = m->dtxt;
+    if (numel) *numel = (size_t)m->cfg.n_cls * m->cfg.embed_dim;
+    return MUDPT_OK;
+}
+extern "C" int mudpt_cp_forward(mudpt_model* m, const float* images, int32_t B, int32_t flags, void* stream) {
+    TRY(ready(m, B, false));
+    ARG_CHECK(images && !m->cocoop, "cp_forward: null images / not a MuDPT model");
+    const bool reuse = (flags & MUDPT_FWD_REUSE_TEXT) != 0;
+    if (reuse && !m->text_valid) { set_error("cp_forward: MUDPT_FWD_REUSE_TEXT before any text-tower pass"); return MUDPT_ERR_STATE; }
+    TRY(towers_forward(m, images, B, (hipStream_t)stream, reuse));
+    m->cp_B = B; m->cp_stage = 1;
+    return MUDPT_OK;
+}
+extern "C" int mudpt_cp_head(mudpt_model* m, const int64_t* labels, int32_t B, float grad_scale, float* loss, float* logits, int32_t flags, void* stream) {
+    TRY(ready(m, B, labels != nullptr));
+    ARG_CHECK(!m->cocoop && (labels ? loss != nullptr : logits != nullptr), "cp_head: training needs labels and loss, inference needs logits");
+    if (m->cp_stage < 1 || m->cp_B != B) { set_error("cp_head: call mudpt_cp_forward with the same batch first"); return MUDPT_ERR_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    if (!labels) {  // inference: logits only (flags & MUDPT_FWD_REUSE_TEXT: the normalised table of the previous call)
+        TRY(head_forward(m, B, (flags & MUDPT_FWD_REUSE_TEXT) != 0, s));
+        HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * m->cfg.n_cls * 4, hipMemcpyDeviceToDevice, s));
+        m->cp_stage = 0;
+        return MUDPT_OK;
+    }
+    HIP_TRY(hipMemsetAsync(m->grads, 0, m->total * 4, s));
+    TRY(head_train(m, labels, B, grad_scale, loss, logits, s));
+    m->cp_stage = 2;
+    return MUDPT_OK;
+}
+extern "C" int mudpt_cp_backward(mudpt_model* m, int32_t part, void* stream) {
+    ARG_CHECK(m && !m->cocoop && (part == MUDPT_CP_VISION || part == MUDPT_CP_TEXT), "cp_backward: part must be MUDPT_CP_VISION or MUDPT_CP_TEXT");
+    hipStream_t s = (hipStream_t)stream;
+    if (part == MUDPT_CP_VISION) {
+        if (m->cp_stage != 2) { set_error("cp_backward: call mudpt_cp_head (training) first"); return MUDPT_ERR_STATE; }
+        TRY(vision_backward(m, m->cp_B, m->cp_unscale, s));
+        m->cp_stage = 3;
+        return MUDPT_OK;
+    }
+    if (m->cp_stage != 3) { set_error("cp_backward: the vision part comes first"); return MUDPT_ERR_STATE; }
+    TRY(text_backward(m, m->cp_unscale, s));  // on the caller's stream: ordered behind its exchange of dfeat
+    m->cp_stage = 0;
+    return prompt_learner_backward(m, s);
 }
 
 extern "C" int mudpt_sgd_step(mudpt_model* m, float lr, float momentum, float wd, float dampening, int32_t nesterov, void* stream) {
@@ -1273,7 +1403,7 @@ extern "C" int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch,
     };
     ARG_CHECK(batch > 0 && batch <= c.max_batch, "debug_read: bad batch %d", batch);
     if (k.rfind("vis.", 0) == 0) tower(m->vis, k.substr(4), batch);
-    else if (k.rfind("txt.", 0) == 0) tower(m->txt, k.substr(4), c.n_cls);
+    else if (k.rfind("txt.", 0) == 0) tower(m->txt, k.substr(4), m->ct);  // this handle's classes
     else if (k == "image_features") { src = m->img_f; n = (size_t)batch * c.embed_dim; }
     else if (k == "text_features") { src = m->txt_f; n = (size_t)c.n_cls * c.embed_dim; }
     ARG_CHECK(src, "debug_read: unknown tensor '%s'", name);

@@ -57,7 +57,8 @@ class _Holder(nn.Module):
 class CustomCLIP(nn.Module):
     def __init__(self, shape: ModelShape, clip_state: Dict[str, torch.Tensor], tokenized_prompts: torch.Tensor,
                  ctx_token_ids: Optional[Sequence[int]] = None, max_batch: int = 256, dtype: str = "bf16",
-                 device: str = "cuda:0", seed: Optional[int] = None, variant: str = "mudpt", knobs: Optional[Dict[str, int]] = None):
+                 device: str = "cuda:0", seed: Optional[int] = None, variant: str = "mudpt", knobs: Optional[Dict[str, int]] = None,
+                 class_shard: Optional[Sequence[int]] = None, group=None):
         super().__init__()
         if not torch.cuda.is_available():
             raise capi.MudptError("mudpt_amd needs an MI355X (HIP device); there is no CPU path in the product")
@@ -87,6 +88,13 @@ class CustomCLIP(nn.Module):
                 continue
             t = v.detach().to("cpu", torch.float32).contiguous()
             capi.check(self.lib.mudpt_set_weight(h, k.encode(), capi.ptr(t), t.numel()), f"set_weight({k})")
+        # class-parallel text tower (include/mudpt.h): this rank encodes classes [c0, c1) of the n_cls; ``group`` is the process group
+        # of the two exchanges (None = the default group)
+        self.class_shard, self.group = None, group
+        if class_shard is not None and tuple(class_shard) != (0, self.n_cls):
+            assert variant == "mudpt", "CoCoOp's text features depend on the image: shard the batch, not the classes"
+            self.class_shard = (int(class_shard[0]), int(class_shard[1]))
+            capi.check(self.lib.mudpt_set_class_shard(h, *self.class_shard), "set_class_shard")
         # class prompts: token_embedding(tokenized) and the EOT position (trainers/mudpt.py:85-90,154)
         emb_w = clip_state["token_embedding.weight"].detach().to("cpu", torch.float32)
         tok = tokenized_prompts.to("cpu").long()
@@ -115,6 +123,11 @@ class CustomCLIP(nn.Module):
             mod.register_parameter(leaf, p)
             self.param_names.append(key)
         self._init_trainables(emb_w, ctx_token_ids, seed)
+        self._cp_feat = self._cp_dfeat = None
+        if variant == "mudpt":  # the [n_cls, embed] text-feature table and its gradient (library-owned): operands of the class-parallel exchanges
+            f, df, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+            capi.check(self.lib.mudpt_cp_buffers(h, C.byref(f), C.byref(df), C.byref(n)), "cp_buffers")
+            self._cp_feat, self._cp_dfeat = (capi.device_view(q.value, n.value, self.device).view(self.n_cls, shape.embed_dim) for q in (f, df))
         self._loss = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._text_version = None  # flat_params._version the library's cached text features belong to
 
@@ -181,13 +194,50 @@ class CustomCLIP(nn.Module):
         # counter moved (the reference re-runs the text tower for every test batch)
         version = self.flat_params._version
         reuse = (not self.training) and self._text_version == version and self.variant == "mudpt"  # CoCoOp's text features depend on the image
-        capi.check(self.lib.mudpt_forward_ex(self._h, capi.ptr(image), B, capi.ptr(logits), 1 if reuse else 0, self._stream()), "forward")
+        if self.class_shard is not None:
+            capi.check(self.lib.mudpt_cp_forward(self._h, capi.ptr(image), B, 1 if reuse else 0, self._stream()), "cp_forward")
+            if not reuse:
+                self._exchange(self._cp_feat)
+            capi.check(self.lib.mudpt_cp_head(self._h, None, B, 1.0, None, capi.ptr(logits), 1 if reuse else 0, self._stream()), "cp_head")
+        else:
+            capi.check(self.lib.mudpt_forward_ex(self._h, capi.ptr(image), B, capi.ptr(logits), 1 if reuse else 0, self._stream()), "forward")
         self._text_version = version
         return logits
+
+    def _exchange(self, table: torch.Tensor, async_op: bool = False):
+        """Sum of a [n_cls, embed] table over the ranks of the class-parallel group (rows of other ranks are zero in the feature table,
+        so the sum is the gather, bit for bit, also for uneven shards)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return dist.all_reduce(table, group=self.group, async_op=async_op)
+        return None
+
+    def forward_backward_cp(self, image: torch.Tensor, label: torch.Tensor, grad_scale: float = 1.0, return_logits: bool = False):
+        """The training step in class-parallel phases (include/mudpt.h): towers forward with this rank's classes -> sum of the feature
+        table -> head over the local images and all classes -> sum of d(features), overlapped with the vision backward -> text backward
+        over this rank's classes.  Also valid on an unsharded handle / one rank (no exchange happens)."""
+        self._check_images(image)
+        assert label.shape == (image.shape[0],), f"labels must be [B], got {tuple(label.shape)}"
+        image = image.to(self.device, torch.float32).contiguous()
+        label = label.to(self.device, torch.int64).contiguous()
+        B = image.shape[0]
+        logits = torch.empty(B, self.n_cls, dtype=torch.float32, device=self.device) if return_logits else None
+        capi.check(self.lib.mudpt_cp_forward(self._h, capi.ptr(image), B, 0, self._stream()), "cp_forward")
+        self._exchange(self._cp_feat)
+        capi.check(self.lib.mudpt_cp_head(self._h, capi.ptr(label), B, grad_scale, capi.ptr(self._loss), capi.ptr(logits), 0, self._stream()), "cp_head")
+        work = self._exchange(self._cp_dfeat, async_op=True)
+        capi.check(self.lib.mudpt_cp_backward(self._h, capi.CP_VISION, self._stream()), "cp_backward(vision)")
+        if work is not None:
+            work.wait()  # the current stream waits for the collective; the host does not
+        capi.check(self.lib.mudpt_cp_backward(self._h, capi.CP_TEXT, self._stream()), "cp_backward(text)")
+        self._text_version = self.flat_params._version
+        return (self._loss[0], logits) if return_logits else self._loss[0]
 
     # -- trainers/mudpt.py:249-251 minus the optimizer step: loss (device scalar) + .grad of the 10 tensors ---------------
     def forward_backward(self, image: torch.Tensor, label: torch.Tensor, grad_scale: float = 1.0,
                          return_logits: bool = False):
+        if self.class_shard is not None:
+            return self.forward_backward_cp(image, label, grad_scale, return_logits)
         self._check_images(image)
         assert label.shape == (image.shape[0],), f"labels must be [B], got {tuple(label.shape)}"
         image = image.to(self.device, torch.float32).contiguous()

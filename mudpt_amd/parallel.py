@@ -69,6 +69,18 @@ def broadcast_params(flat_params: torch.Tensor, src: int = 0) -> torch.Tensor:
     return flat_params
 
 
+def class_range(n_cls: int, r: int | None = None, world: int | None = None) -> Tuple[int, int]:
+    """Rank r's contiguous share [c0, c1) of the class prompts for the class-parallel text tower (include/mudpt.h, SURVEY 8e second
+    axis): balanced to within one class; with more ranks than classes the surplus ranks share the last class (every handle encodes
+    at least one; the exchange is a sum, so a class held twice must not happen -- callers use world <= n_cls)."""
+    r = rank() if r is None else r
+    world = world_size() if world is None else world
+    assert 0 < world <= n_cls, f"class-parallel text tower needs world ({world}) <= n_cls ({n_cls})"
+    base, extra = divmod(n_cls, world)
+    c0 = r * base + min(r, extra)
+    return c0, c0 + base + (1 if r < extra else 0)
+
+
 def shard_batch(image: torch.Tensor, label: torch.Tensor):
     """This rank's contiguous slice of a global batch, as ``nn.DataParallel``'s scatter along dim 0 gives GPU k
     (trainers/mudpt.py:230-233).  Dassl's loaders are not rank-aware: launched under torch.distributed.run every rank draws the
