@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning knob passed to mudpt_model_set (A/B runs on one box)")
     ap.add_argument("--attn-two-kernels", action="store_true", help="attention backward as the round-1 dQ + dK/dV kernel pair (A/B of the single-sweep kernel)")
     ap.add_argument("--no-last-single", action="store_true", help="last block through the general attention kernels on all rows (A/B of the single-query path)")
+    ap.add_argument("--class-parallel", action="store_true", help="N > 1: each rank encodes C / N class prompts (two extra [C, embed] sums per step); "
+                    "meant for --classes 1000 (BASELINE configs[2])")
     ap.add_argument("--fp32-streams", action="store_true", help="keep the update / gradient streams in fp32 (A/B of the bf16 streams)")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a captured hipGraph (implies --no-profile)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the short fp16 (parity configuration) timing appended to the bf16 line")
@@ -108,7 +110,7 @@ def main():
         dist.init_process_group(os.environ.get("MUDPT_BENCH_BACKEND", "nccl"))  # "nccl" is RCCL over xGMI on ROCm
 
     from mudpt_amd.model import CustomCLIP, ModelShape
-    from mudpt_amd import synth, capi
+    from mudpt_amd import synth, capi, parallel
     knobs = {}
     if args.gemm_variant:
         knobs["gemm_variant"] = args.gemm_variant
@@ -124,7 +126,8 @@ def main():
     B, C = args.batch, args.classes
     tok = synth.bench_tokenized_prompts() if C == 11 else synth.synthetic_tokenized_prompts(C)
     model = CustomCLIP(shape, synth.random_clip_state(shape, seed=0), tok, ctx_token_ids=synth.CTX_INIT_TOKENS,
-                       max_batch=B, dtype=args.dtype, device=f"cuda:{local}", seed=1, knobs=knobs)  # same seeds on every rank: replicas
+                       max_batch=B, dtype=args.dtype, device=f"cuda:{local}", seed=1, knobs=knobs,  # same seeds on every rank: replicas
+                       class_shard=parallel.class_range(C, rank, world) if args.class_parallel and world > 1 else None)
     g = torch.Generator().manual_seed(1234 + rank)
     images = torch.randn(B, 3, shape.image_size, shape.image_size, generator=g).cuda()
     labels = torch.randint(0, C, (B,), generator=g).cuda()
@@ -236,7 +239,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"MuDPT {'ViT-B/16' if args.arch == 'vit_b16' else 'ViT-L/14@336'} fwd+bwd+SGD, batch {B}/GPU, {C} class prompts, n_ctx {shape.n_ctx}, depth {shape.depth}, "
                                    f"synthetic {shape.image_size}x{shape.image_size} N(0,1) images, random-init frozen CLIP (BASELINE configs[{1 if args.arch == 'vit_b16' else 4}])",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss_v, 4),
+                       "global_batch": world * B, "parallelism": f"dp{world}" + ("+class-parallel text tower" if args.class_parallel and world > 1 else ""), "final_loss": round(loss_v, 4),
                        "step_tflop": round(step_flop / 1e12, 3)},
         }
         traffic_db = json.load(open(TRAFFIC_JSON)).get("classes", {}) if os.path.exists(TRAFFIC_JSON) and B == 256 and C == 11 and args.dtype == "bf16" and args.arch == "vit_b16" else {}

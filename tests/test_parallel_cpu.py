@@ -161,3 +161,30 @@ def test_single_process_is_a_noop():
     assert parallel.world_size() == 1 and parallel.grad_scale() == 1.0
     assert torch.equal(parallel.allreduce_grads(t.clone()), t) and torch.equal(parallel.broadcast_params(t.clone()), t)
     assert list(parallel.shard(10, 1, 4)) == [2, 3] and list(parallel.shard(8, 3, 4)) == [6, 7]
+
+
+def test_class_range_partitions_the_classes():
+    """Class-parallel text tower: contiguous, balanced, disjoint, covering; refuses more ranks than classes."""
+    from mudpt_amd import parallel
+    for n_cls, world in [(11, 2), (1000, 8), (208, 3), (8, 8)]:
+        r = [parallel.class_range(n_cls, k, world) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == n_cls
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        sizes = [b - a for a, b in r]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+    with pytest.raises(AssertionError):
+        parallel.class_range(3, 0, 4)
+
+
+def test_class_parallel_setting(monkeypatch):
+    """The plugin's switch: off for one process whatever the setting; "auto" needs >= 256 classes."""
+    from mudpt_amd import trainer, parallel
+    monkeypatch.setattr(parallel, "world_size", lambda: 1)
+    assert trainer.class_parallel_shard(1000, True) is None
+    monkeypatch.setattr(parallel, "world_size", lambda: 4)
+    monkeypatch.setattr(parallel, "rank", lambda: 1)
+    assert trainer.class_parallel_shard(1000, None) == (250, 500)
+    assert trainer.class_parallel_shard(11, None) is None and trainer.class_parallel_shard(11, "1") == (3, 6)
+    assert trainer.class_parallel_shard(1000, "off") is None
+    monkeypatch.setenv("MUDPT_CLASS_PARALLEL", "0")
+    assert trainer.class_parallel_shard(1000, None) is None
