@@ -79,6 +79,10 @@ int mudpt_set_weight(mudpt_model* m, const char* key, const float* host_data, si
  * positions 0..max(eot_index) only: under the causal mask (clip/model.py:407-413) later positions reach neither the EOT
  * feature (trainers/mudpt.py:154) nor any gradient. */
 int mudpt_set_class_prompts(mudpt_model* m, const float* embedding, const int32_t* eot_index);
+/* What the text tower runs per pass after mudpt_set_class_prompts: token rows, length buckets, longest kept length.  With many classes
+ * (>= 2048 rows) the prompts are sorted by length and run in up to "txt_buckets" (mudpt_model_set, default 3) groups, each to its own
+ * longest EOT, instead of all to the overall longest: the kept rows are bit-identical, the padding rows are not computed. */
+int mudpt_text_layout(const mudpt_model* m, int32_t* rows, int32_t* buckets, int32_t* max_len);
 
 /* The 10 trainable tensors live in ONE flat fp32 bucket (= the data-parallel all-reduce payload). */
 int mudpt_param_count(const mudpt_model* m);   /* 10 (MuDPT) or 5 (CoCoOp) */
@@ -153,7 +157,9 @@ int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* hos
  * models in one process do not interfere: "gemm_variant"; "last_single" (0 = the last block's attention on all rows instead of the
  * single-query form); "attn_two_kernels" (1 = attention backward as two kernels); "cocoop_chunk"
  * (cap on the images per CoCoOp text-tower pass; read by the next mudpt_set_class_prompts); "lp_grad" (bf16 mode: 0 keeps the gradient / update streams in fp32);
- * "prof_stride" (measurement mode brackets every prof_stride-th persistent-GEMM launch, counted across steps);
+ * "txt_buckets" (maximum number of length buckets
+ * of the class prompts, 1 = none) and "txt_bucket_cost" (token rows one more bucket must save, default 1024; both read by the next
+ * mudpt_set_class_prompts); "prof_stride" (measurement mode brackets every prof_stride-th persistent-GEMM launch, counted across steps);
  * "txt_split" (fp16 mode: 0 = no split operands in the text tower; only before the first mudpt_set_weight); "txt_trim"
  * (0 = run the text tower on all ctx_len positions; read by the next mudpt_set_class_prompts, which must follow). */
 int mudpt_model_set(mudpt_model* m, const char* name, int32_t value);

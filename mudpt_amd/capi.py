@@ -46,6 +46,7 @@ SIGNATURES = {
     "mudpt_sgd_step": (_i32, [_vp, _f32, _f32, _f32, _f32, _i32, _vp]),
     "mudpt_sgd_reset": (_i32, [_vp]),
     "mudpt_allreduce_grads": (_i32, [_vp, _vp, _vp]),
+    "mudpt_text_layout": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "mudpt_set_class_shard": (_i32, [_vp, _i32, _i32]),
     "mudpt_cp_buffers": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
     "mudpt_cp_forward": (_i32, [_vp, _vp, _i32, _i32, _vp]),

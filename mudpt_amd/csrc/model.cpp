@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -102,7 +103,22 @@ struct Tower {
     int head_n = 0;                  // rows per sequence
     void *hd_dqkv = nullptr, *hd_h = nullptr;  // T [max_seq * n_ctx, 3 d], [max_seq * n_ctx, d]
     std::vector<void*> act_allocs;  // activation / scratch buffers (sized for max_seq sequences of L rows): re-made when L changes
+    // Length buckets (text tower with many classes): the sequences are sorted by length and packed bucket after bucket, each bucket with
+    // its own row count per sequence, so the row-wise kernels (GEMMs, LayerNorm) run once over `rows` packed rows while the kernels that
+    // know about sequences (attention, prompt splice, prompt-row reductions) run once per bucket.  Empty = one bucket of max_seq x L.
+    struct Seg { int row0 = 0, seq0 = 0, nseq = 0, L = 0; size_t lse0 = 0; };
+    std::vector<Seg> segs;
+    int rows = 0;                        // packed rows (segs non-empty)
+    const int* tail_local = nullptr;     // [nseq] tail row of a sequence relative to its bucket's first row (single-query attention)
 };
+
+// rows of a tower pass over nseq sequences; its buckets (one pseudo-bucket when the tower is not packed)
+static int tower_rows(const Tower& t, int nseq) { return t.segs.empty() ? nseq * t.L : t.rows; }
+static std::vector<Tower::Seg> tower_segs(const Tower& t, int nseq) {
+    if (!t.segs.empty()) return t.segs;
+    Tower::Seg one; one.nseq = nseq; one.L = t.L;
+    return {one};
+}
 
 }  // namespace mudpt
 
@@ -129,6 +145,8 @@ struct mudpt_model {
     float *tpos = nullptr, *ln_fin_g = nullptr, *ln_fin_b = nullptr, *tproj = nullptr;
     float* emb_pos = nullptr;  // [C, Lt, dt] class token embeddings + positional embedding
     int *eot_rows = nullptr, *tprompt_rows = nullptr;
+    int *eot_local = nullptr, *class_perm = nullptr;  // EOT row relative to the sequence's length bucket; packed position -> local class
+    float *txt_sorted = nullptr, *dtxt_sorted = nullptr;  // [C, e] text features / their gradient in packed (length-sorted) order
     float *t_ln = nullptr, *fin_mean = nullptr, *fin_rstd = nullptr, *dt_ln = nullptr;
     float scale = 1.f;
     // prompt learner intermediates (fp32)
@@ -161,6 +179,8 @@ struct mudpt_model {
     // per-handle tuning knobs (mudpt_model_set): nothing here is process-global, two models in one process do not interfere
     int gemm_variant = 0;
     bool txt_trim = true;  // run the text tower on positions 0..max(eot) only (read by mudpt_set_class_prompts)
+    int txt_bucket_cost = 1024;  // knob: what one more bucket costs in the cut search, in token rows (its extra launches per block)
+    int txt_buckets = 3;   // knob: at most this many length buckets for the class prompts (1 = every prompt runs to the longest EOT)
     bool attn_fused_w1 = false;
     bool last_single = true;  // knob: single-query attention in the last block (0 = the general kernels on all rows)
     bool attn_two_kernels = false;  // knob: attention backward as the dQ + dK/dV kernel pair instead of the fused single pass
@@ -414,7 +434,8 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
         ALLOC(m->cls_rows, B * 4); ALLOC(m->vprompt_rows, (size_t)B * n * 4);
         ALLOC(m->tpos, (size_t)c->ctx_len * dt * 4); ALLOC(m->ln_fin_g, dt * 4); ALLOC(m->ln_fin_b, dt * 4);
         ALLOC(m->tproj, (size_t)dt * e * 4);
-        ALLOC(m->emb_pos, (size_t)C * c->ctx_len * dt * 4); ALLOC(m->eot_rows, TS * 4);
+        ALLOC(m->emb_pos, (size_t)C * c->ctx_len * dt * 4); ALLOC(m->eot_rows, TS * 4); ALLOC(m->eot_local, TS * 4); ALLOC(m->class_perm, C * 4);
+        ALLOC(m->txt_sorted, (size_t)C * e * 4); ALLOC(m->dtxt_sorted, (size_t)C * e * 4);
         ALLOC(m->t_ln, (size_t)TS * dt * 4); ALLOC(m->fin_mean, TS * 4); ALLOC(m->fin_rstd, TS * 4); ALLOC(m->dt_ln, (size_t)TS * dt * 4);
         const size_t dn = (size_t)(D1 > 0 ? D1 : 1) * n;
         ALLOC(m->shared, (size_t)n * dv * 4); ALLOC(m->t2v, dn * dv * 4); ALLOC(m->v2t, dn * e * 4);
@@ -629,21 +650,94 @@ extern "C" int mudpt_set_class_prompts(mudpt_model* m, const float* emb, const i
     }
     m->txt_chunk = (int)chunk;
     if (int rc = alloc_tower_acts(m, m->txt, (int)Le, (int)(m->cocoop ? chunk * C : C))) return rc;
-    std::vector<float> pos(L * d), ep(C * Le * d);
+    // Length buckets (MuDPT, many classes): "a photo of a <name>." ends at position 7-9 for most ImageNet names and at 19 for a few; the
+    // trim above runs EVERY prompt to the longest.  Sorting the prompts by length and cutting the sorted list into <= txt_buckets groups,
+    // each run to its own longest member, removes most of the padding (C = 1000 synthetic names: 19 000 -> ~11 000 rows).  Sequences are
+    // independent in every kernel of the tower, so the kept rows are bit-identical to the single-bucket run (tests).  A bucket costs a
+    // handful of extra launches per block (attention, splice, reductions: ~1 000 rows' worth of time), which the cut search charges.
+    Tower& X = m->txt;
+    X.segs.clear();
+    std::vector<int> order(C);  // packed position -> local class
+    for (size_t cc = 0; cc < C; ++cc) order[cc] = (int)cc;
+    auto len_of = [&](int cc) { return std::max(eot[cc] + 1, c.n_ctx + 2); };
+    if (!m->cocoop && m->txt_trim && m->txt_buckets > 1 && C * Le >= 2048) {
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return len_of(x) < len_of(y); });
+        std::vector<int> dl, cnt;  // distinct lengths ascending, sequences per length
+        for (int cc : order) {
+            if (dl.empty() || dl.back() != len_of(cc)) { dl.push_back(len_of(cc)); cnt.push_back(0); }
+            ++cnt.back();
+        }
+        const int nd = (int)dl.size(), K = std::min(m->txt_buckets, nd);
+        const long PEN = m->txt_bucket_cost, INF = 1L << 60;
+        std::vector<long> pre(nd + 1, 0);
+        for (int j = 0; j < nd; ++j) pre[j + 1] = pre[j] + cnt[j];
+        // best[b][j]: rows (+ penalties) of covering lengths 0..j-1 with b buckets, the last one ending at length j-1
+        std::vector<std::vector<long>> best(K + 1, std::vector<long>(nd + 1, INF));
+        std::vector<std::vector<int>> from(K + 1, std::vector<int>(nd + 1, 0));
+        best[0][0] = 0;
+        for (int bk = 1; bk <= K; ++bk)
+            for (int j = 1; j <= nd; ++j)
+                for (int i0 = bk - 1; i0 < j; ++i0) {
+                    if (best[bk - 1][i0] >= INF) continue;
+                    const long v = best[bk - 1][i0] + (pre[j] - pre[i0]) * dl[j - 1] + PEN;
+                    if (v < best[bk][j]) { best[bk][j] = v; from[bk][j] = i0; }
+                }
+        int kb = 1;
+        for (int bk = 2; bk <= K; ++bk) if (best[bk][nd] < best[kb][nd]) kb = bk;
+        if (kb > 1) {
+            std::vector<int> cuts;  // bucket boundaries in distinct-length indices
+            for (int bk = kb, j = nd; bk >= 1; --bk) { cuts.push_back(j); j = from[bk][j]; }
+            std::reverse(cuts.begin(), cuts.end());
+            int j0 = 0, row0 = 0;
+            size_t lse0 = 0;
+            for (int j1 : cuts) {
+                Tower::Seg g; g.row0 = row0; g.seq0 = (int)pre[j0]; g.nseq = (int)(pre[j1] - pre[j0]); g.L = dl[j1 - 1]; g.lse0 = lse0;
+                X.segs.push_back(g);
+                row0 += g.nseq * g.L;
+                lse0 += (size_t)g.nseq * X.heads * attn_padded_len(g.L);
+                j0 = j1;
+            }
+            X.rows = row0;
+        } else {
+            for (size_t cc = 0; cc < C; ++cc) order[cc] = (int)cc;  // one bucket: keep the caller's order
+        }
+    }
+    std::vector<float> pos(L * d);
     HIP_TRY(hipMemcpy(pos.data(), m->tpos, pos.size() * 4, hipMemcpyDeviceToHost));
     const size_t reps = chunk;  // CoCoOp: sequence i * C + c for every image i of a chunk (the tables are chunk-local, reused per chunk)
-    std::vector<int> rows(C * reps), tr(C * reps * c.n_ctx);
-    for (size_t cc = 0; cc < C; ++cc) {
-        for (size_t i = 0; i < reps; ++i) rows[i * C + cc] = (int)((i * C + cc) * Le) + eot[cc];
-        for (size_t i = 0; i < Le * d; ++i) ep[cc * Le * d + i] = emb[cc * L * d + i] + pos[i];  // trainers/mudpt.py:143
-    }
-    for (size_t sq = 0; sq < C * reps; ++sq)
-        for (int i = 0; i < c.n_ctx; ++i) tr[sq * c.n_ctx + i] = (int)(sq * Le) + 1 + i;  // ctx rows 1..n (trainers/mudpt.py:97-115)
+    const std::vector<Tower::Seg> segs = tower_segs(X, (int)C);
+    const size_t packed_rows = X.segs.empty() ? C * Le : (size_t)X.rows;
+    std::vector<float> ep(packed_rows * d);
+    std::vector<int> rows(C * reps), rows_local(C * reps), tr(C * reps * c.n_ctx), perm(C);
+    for (const Tower::Seg& g : segs)
+        for (int j = 0; j < g.nseq; ++j) {
+            const int sq = g.seq0 + j, cc = order[sq];
+            const size_t r0 = (size_t)g.row0 + (size_t)j * g.L;
+            perm[sq] = cc;
+            for (size_t i = 0; i < reps; ++i) {  // reps > 1 (CoCoOp) only with one bucket: image i's prompts follow image i - 1's
+                rows[i * C + sq] = (int)(i * C * Le + r0) + eot[cc];
+                rows_local[i * C + sq] = (int)(i * C * Le + r0 - g.row0) + eot[cc];
+                for (int k = 0; k < c.n_ctx; ++k) tr[(i * C + sq) * c.n_ctx + k] = (int)(i * C * Le + r0) + 1 + k;  // ctx rows 1..n (trainers/mudpt.py:97-115)
+            }
+            for (size_t i = 0; i < (size_t)g.L * d; ++i) ep[r0 * d + i] = emb[(size_t)cc * L * d + i] + pos[i];  // trainers/mudpt.py:143
+        }
     HIP_TRY(hipMemcpy(m->emb_pos, ep.data(), ep.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->eot_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->eot_local, rows_local.data(), rows_local.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->tprompt_rows, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->class_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
+    X.tail_local = m->eot_local;
     m->prompts_set = true;
     m->text_valid = false;
+    return MUDPT_OK;
+}
+
+extern "C" int mudpt_text_layout(const mudpt_model* m, int32_t* rows, int32_t* buckets, int32_t* max_len) {
+    ARG_CHECK(m && m->prompts_set, "text_layout: call mudpt_set_class_prompts first");
+    const int nseq = m->cocoop ? m->txt_chunk * m->cfg.n_cls : m->ct;
+    if (rows) *rows = tower_rows(m->txt, nseq);
+    if (buckets) *buckets = m->txt.segs.empty() ? 1 : (int)m->txt.segs.size();
+    if (max_len) *max_len = m->txt.L;
     return MUDPT_OK;
 }
 
@@ -732,7 +826,8 @@ static int block_fwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s, boo
 // vmcnt retires in order).  So LN1 of block i >= 1 computes x_in[i] = x_mid[i-1] + upd, with the deep-prompt rows
 // spliced in (splice != null), and writes it for the backward; LN2 computes x_mid[i] = x_in[i] + upd.
 static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* splice, hipStream_t s) {
-    const int M = nseq * t.L, d = t.d, dt = m->dtype, n = m->cfg.n_ctx;
+    const int M = tower_rows(t, nseq), d = t.d, dt = m->dtype, n = m->cfg.n_ctx;
+    const std::vector<Tower::Seg> segs = tower_segs(t, nseq);
     // bf16 mode: the update stream (out_proj / c_proj results) is kept in T like the gradient stream -- half the store time
     // of those GEMMs and 2 bytes less per element in the LayerNorm that adds it.  The last block's c_proj stays fp32 (launch_add).
     const bool lp = m->lp_grad;
@@ -747,7 +842,22 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
         if (lp) l1.add_lp = t.upd; else l1.add = t.upd;
         if (splice) { l1.ov_rows = splice; l1.ov_row0 = t.prompt_row0; l1.ov_n = n; l1.ov_L = t.L; }
     }
-    TRY(ln_fwd_call(m, t, l1, s));
+    if (splice && i > 0 && segs.size() > 1) {
+        // the splice replaces rows by their position inside a sequence: one launch per length bucket
+        for (const Tower::Seg& g : segs) {
+            LnFwdArgs b = l1;
+            const size_t r0 = (size_t)g.row0;
+            b.x = l1.x + r0 * l1.ldx; b.xout = l1.xout + r0 * l1.ldxout;
+            if (l1.add) b.add = l1.add + r0 * l1.ldadd;
+            if (l1.add_lp) b.add_lp = (const char*)l1.add_lp + r0 * l1.ldadd * esz;
+            b.out = (char*)l1.out + r0 * l1.ldo * esz;
+            if (l1.out_lo) b.out_lo = (char*)l1.out_lo + r0 * l1.ldo * esz;
+            b.mean = l1.mean + r0; b.rstd = l1.rstd + r0; b.rows = g.nseq * g.L; b.ov_L = g.L;
+            TRY(ln_fwd_call(m, t, b, s));
+        }
+    } else {
+        TRY(ln_fwd_call(m, t, l1, s));
+    }
     if (i + 1 == t.layers && m->last_single && t.tail_rows) {
         // Last block: only ONE query per sequence is ever used (CLS / EOT row).  K and V for every row (the k, v thirds of in_proj: rows
         // d .. 3d of its weight, written into the k, v thirds of the packed qkv buffer), q for the selected rows only, single-query attention
@@ -760,15 +870,23 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
         GemmArgs qs; qs.A = t.h_sel; qs.lda = sp * d; qs.B = t.split ? w.w_in2 : w.w_in; qs.ldb = sp * d; qs.M = nseq; qs.N = d; qs.K = sp * d; qs.bias = w.b_in;
         qs.out0 = t.q_sel; qs.ldo0 = d;
         TRY(gemm_call(m, EPI_STORE, qs, s));
-        AttnArgs at; at.qkv = a.qkv; at.sel_rows = t.tail_rows; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
-        TRY(launch_attn_fwd_single(dt, at, t.q_sel, t.attn_sel, t.split ? (char*)t.attn_sel + (size_t)d * esz : nullptr, sp * d, t.lse_sel, s));
+        for (const Tower::Seg& g : segs) {
+            AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
+            at.sel_rows = segs.size() > 1 ? t.tail_local + g.seq0 : t.tail_rows;
+            char* osel = (char*)t.attn_sel + (size_t)g.seq0 * sp * d * esz;
+            TRY(launch_attn_fwd_single(dt, at, (const char*)t.q_sel + (size_t)g.seq0 * d * esz, osel, t.split ? osel + (size_t)d * esz : nullptr, sp * d,
+                                       t.lse_sel + (size_t)g.seq0 * t.heads, s));
+        }
         return block_fwd_tail(m, t, nseq, s, true);
     }
     GemmArgs q; q.A = t.h; q.lda = sp * d; q.B = t.split ? w.w_in2 : w.w_in; q.ldb = sp * d; q.M = M; q.N = 3 * d; q.K = sp * d; q.bias = w.b_in; q.out0 = a.qkv; q.ldo0 = 3 * d;
     TRY(gemm_call(m, EPI_STORE, q, s));
-    AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
-    if (t.split) { at.ld_out = 2 * d; at.out_lo = (char*)a.attn + (size_t)d * esz; }
-    TRY(attn_call(m, t, at, false, s));
+    for (const Tower::Seg& g : segs) {
+        AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * sp * d * esz; at.lse = a.lse + g.lse0;
+        at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
+        if (t.split) { at.ld_out = 2 * d; at.out_lo = (char*)at.out + (size_t)d * esz; }
+        TRY(attn_call(m, t, at, false, s));
+    }
     if (i + 1 == t.layers) return block_fwd_tail(m, t, nseq, s);
     GemmArgs o; o.A = a.attn; o.lda = sp * d; o.B = t.split ? w.w_out2 : w.w_out; o.ldb = sp * d; o.M = M; o.N = d; o.K = sp * d; o.bias = w.b_out; o.out0 = t.upd; o.ldo0 = d;
     TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, o, s));
@@ -788,7 +906,8 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
 // Backward of the last block's tail (see Tower::tail_rows).  in: t.dsel / t.dsel_lp = gradient w.r.t. the selected rows of
 // the tower output; out: t.dx / t.dx_lp = gradient w.r.t. the last block's input, all rows.
 static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
-    const int i = t.layers - 1, M = nseq * t.L, S = nseq, d = t.d, dt = m->dtype;
+    const int i = t.layers - 1, M = tower_rows(t, nseq), S = nseq, d = t.d, dt = m->dtype;
+    const std::vector<Tower::Seg> segs = tower_segs(t, nseq);
     const size_t esz = 2;
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
@@ -804,8 +923,15 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     TRY(gemm_call(m, EPI_STORE, g3, s));
     if (m->last_single) {
         // single-query attention backward: dK, dV of every row (k, v thirds of t.dqkv) and dq of the one query per sequence
-        AttnArgs at; at.qkv = a.qkv; at.sel_rows = t.tail_rows; at.dqkv = t.dqkv; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
-        TRY(launch_attn_bwd_single(dt, at, t.q_sel, t.attn_sel, (t.split ? 2 : 1) * d, t.dattn_sel, t.lse_sel, t.dq_sel, s));
+        const int spd = (t.split ? 2 : 1) * d;
+        for (const Tower::Seg& g : segs) {
+            AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.dqkv = (char*)t.dqkv + (size_t)g.row0 * 3 * d * esz;
+            at.sel_rows = segs.size() > 1 ? t.tail_local + g.seq0 : t.tail_rows;
+            at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
+            TRY(launch_attn_bwd_single(dt, at, (const char*)t.q_sel + (size_t)g.seq0 * d * esz, (const char*)t.attn_sel + (size_t)g.seq0 * spd * esz, spd,
+                                       (const char*)t.dattn_sel + (size_t)g.seq0 * d * esz, t.lse_sel + (size_t)g.seq0 * t.heads,
+                                       (char*)t.dq_sel + (size_t)g.seq0 * d * esz, s));
+        }
         // d(ln_1 output) = dK, dV rows . W_kv  (K range d .. 3d of the transposed in_proj weight)  +  on the selected rows  dq . W_q
         GemmArgs g4; g4.A = (char*)t.dqkv + (size_t)d * esz; g4.lda = 3 * d; g4.B = (char*)w.w_in_t + (size_t)d * esz; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 2 * d;
         g4.out0 = t.h; g4.ldo0 = d;
@@ -817,10 +943,15 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     // attention backward over all keys: d(attention output) is zero except on the selected query rows
     HIP_TRY(hipMemsetAsync(t.dattn, 0, (size_t)M * d * esz, s));
     TRY(launch_scatter_rows(t.dattn_sel, (size_t)d * esz, t.tail_rows, t.dattn, (size_t)d * esz, S, d * (int)esz, s));
-    AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.dout = t.dattn; at.dqkv = t.dqkv; at.delta = t.delta; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
-    if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
-    at.sel_rows = t.tail_rows;       // d(attention output) is zero except on those rows: the kernels skip the all-zero query blocks
-    TRY(attn_call(m, t, at, true, s));
+    for (const Tower::Seg& g : segs) {
+        const int spd = (t.split ? 2 : 1) * d;
+        AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * spd * esz; at.lse = a.lse + g.lse0;
+        at.dout = (const char*)t.dattn + (size_t)g.row0 * d * esz; at.dqkv = (char*)t.dqkv + (size_t)g.row0 * 3 * d * esz; at.delta = t.delta + g.lse0;
+        at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
+        if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
+        at.sel_rows = segs.size() > 1 ? t.tail_local + g.seq0 : t.tail_rows;  // d(attention output) is zero except on those rows: the kernels skip the all-zero query blocks
+        TRY(attn_call(m, t, at, true, s));
+    }
     GemmArgs g4; g4.A = t.dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 3 * d; g4.out0 = t.h; g4.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g4, s));
     }
@@ -840,7 +971,7 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
 
 // in: t.dx / t.dx_lp = gradient w.r.t. the block output; out: the same buffers = gradient w.r.t. x_in
 static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
-    const int M = nseq * t.L, d = t.d, dt = m->dtype;
+    const int M = tower_rows(t, nseq), d = t.d, dt = m->dtype;
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
     GemmArgs g1; g1.A = t.dx_lp; g1.lda = d; g1.B = w.w_proj_t; g1.ldb = d; g1.M = M; g1.N = 4 * d; g1.K = d; g1.out0 = t.g; g1.ldo0 = 4 * d; g1.aux = a.u; g1.ldaux = 4 * d;
@@ -853,9 +984,14 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
     TRY(ln_bwd_call(m, t, b2, s));
     GemmArgs g3; g3.A = t.dx_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = M; g3.N = d; g3.K = d; g3.out0 = t.dattn; g3.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g3, s));
-    AttnArgs at; at.qkv = a.qkv; at.out = a.attn; at.lse = a.lse; at.dout = t.dattn; at.dqkv = t.dqkv; at.delta = t.delta; at.B = nseq; at.L = t.L; at.H = t.heads; at.causal = t.causal;
-    if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
-    TRY(attn_call(m, t, at, true, s));
+    for (const Tower::Seg& g : tower_segs(t, nseq)) {
+        const size_t esz = 2, spd = (size_t)(t.split ? 2 : 1) * d;
+        AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * spd * esz; at.lse = a.lse + g.lse0;
+        at.dout = (const char*)t.dattn + (size_t)g.row0 * d * esz; at.dqkv = (char*)t.dqkv + (size_t)g.row0 * 3 * d * esz; at.delta = t.delta + g.lse0;
+        at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
+        if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
+        TRY(attn_call(m, t, at, true, s));
+    }
     if (i == 0 && t.head_rows && t.layers > 1) {
         // block 0: d(x_in) on the prompt rows only (Tower::head_rows); the other rows of t.dx / t.dx_lp are left stale and
         // nothing reads them (the splice reductions and ln_pre's backward touch prompt rows only)
@@ -1021,10 +1157,12 @@ static int prompt_learner_forward(mudpt_model* m, hipStream_t s) {
 static int text_forward(mudpt_model* m, hipStream_t s2) {
     const mudpt_config& c = m->cfg;
     const int dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, Ct = m->ct;
-    const int Lt = m->txt.L;
     float* Pm = m->params;
-    HIP_TRY(hipMemcpyAsync(m->txt.a[0].x_in, m->emb_pos, (size_t)Ct * Lt * dt * 4, hipMemcpyDeviceToDevice, s2));
-    TRY(launch_set_rows(m->txt.a[0].x_in, Ct, Lt, dt, 1, n, Pm + m->off[P_CTX], m->tpos + dt, s2));
+    const std::vector<Tower::Seg> segs = tower_segs(m->txt, Ct);
+    const bool packed = segs.size() > 1;
+    HIP_TRY(hipMemcpyAsync(m->txt.a[0].x_in, m->emb_pos, (size_t)tower_rows(m->txt, Ct) * dt * 4, hipMemcpyDeviceToDevice, s2));
+    for (const Tower::Seg& g : segs)
+        TRY(launch_set_rows(m->txt.a[0].x_in + (size_t)g.row0 * dt, g.nseq, g.L, dt, 1, n, Pm + m->off[P_CTX], m->tpos + dt, s2));
     for (int i = 0; i < m->txt.layers; ++i) {
         TRY(block_fwd(m, m->txt, i, Ct, (i >= 1 && i - 1 < D1) ? m->txt_deep + (size_t)(i - 1) * n * dt : nullptr, s2));
     }
@@ -1032,7 +1170,9 @@ static int text_forward(mudpt_model* m, hipStream_t s2) {
     lf.out_f32 = true; lf.mean = m->fin_mean; lf.rstd = m->fin_rstd; lf.rows = Ct; lf.d = dt;
     TRY(launch_ln_fwd(m->dtype, lf, s2));
     if (m->sharded) HIP_TRY(hipMemsetAsync(m->txt_f, 0, (size_t)c.n_cls * e * 4, s2));  // other ranks' rows: zero, so a sum completes the table
-    TRY(launch_sgemm(false, false, Ct, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, m->txt_f + (size_t)m->c0 * e, e, nullptr, s2));
+    float* feat = m->txt_f + (size_t)m->c0 * e;
+    TRY(launch_sgemm(false, false, Ct, e, dt, 1.f, m->t_ln, dt, m->tproj, e, 0.f, packed ? m->txt_sorted : feat, e, nullptr, s2));
+    if (packed) TRY(launch_scatter_rows(m->txt_sorted, (size_t)e * 4, m->class_perm, feat, (size_t)e * 4, Ct, e * 4, s2));  // back to the caller's class order
     m->text_valid = true;
     return MUDPT_OK;
 }
@@ -1125,20 +1265,29 @@ static int head_train(mudpt_model* m, const int64_t* labels, int B, float grad_s
 static int text_backward(mudpt_model* m, float unscale, hipStream_t s2) {
     const mudpt_config& c = m->cfg;
     const int dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1, Ct = m->ct;
-    const int Lt = m->txt.L;
     float* G = m->grads;
     Tower& X = m->txt;
-    TRY(launch_sgemm(false, true, Ct, dt, e, 1.f, m->dtxt + (size_t)m->c0 * e, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s2));
+    const std::vector<Tower::Seg> segs = tower_segs(X, Ct);
+    const float* dfeat = m->dtxt + (size_t)m->c0 * e;
+    if (segs.size() > 1) {  // length buckets: the tower's sequences are in length-sorted order
+        TRY(launch_gather_rows(dfeat, (size_t)e * 4, m->class_perm, m->dtxt_sorted, (size_t)e * 4, Ct, e * 4, s2));
+        dfeat = m->dtxt_sorted;
+    }
+    TRY(launch_sgemm(false, true, Ct, dt, e, 1.f, dfeat, e, m->tproj, e, 0.f, m->dt_ln, dt, nullptr, s2));
     LnBwdArgs bf; bf.dy = m->dt_ln; bf.lddy = dt; bf.dy_f32 = true; bf.x = X.xout_sel; bf.ldx = dt; bf.mean = m->fin_mean; bf.rstd = m->fin_rstd;
     bf.gamma = m->ln_fin_g; bf.dx = m->lp_grad ? nullptr : X.dsel; bf.lddx = dt; bf.dx_lp = X.dsel_lp; bf.lddx_lp = dt; bf.rows = Ct; bf.d = dt;
     TRY(launch_ln_bwd(m->dtype, bf, s2));
     for (int i = X.layers - 1; i >= 0; --i) {
         if (i == X.layers - 1) TRY(block_bwd_tail(m, X, Ct, s2)); else TRY(block_bwd(m, X, i, Ct, s2));
         if (i >= 1 && i - 1 < D1)
-            TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, X.dx_lp, Ct, Lt, dt, 1, n, m->d_txt_deep + (size_t)(i - 1) * n * dt, true, false, unscale, s2));
+            for (const Tower::Seg& g : segs)  // bucket after bucket in a fixed order: deterministic
+                TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx + (size_t)g.row0 * dt, (char*)X.dx_lp + (size_t)g.row0 * dt * 2, g.nseq, g.L, dt, 1, n,
+                                       m->d_txt_deep + (size_t)(i - 1) * n * dt, true, g.seq0 > 0, unscale, s2));
     }
     // d ctx (text side): rows 1..n of the first block's input, summed over the class prompts
-    TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx, m->lp_grad ? X.dx_lp : nullptr, Ct, Lt, dt, 1, n, G + m->off[P_CTX], false, true, unscale, s2));
+    for (const Tower::Seg& g : segs)
+        TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : X.dx + (size_t)g.row0 * dt, m->lp_grad ? (char*)X.dx_lp + (size_t)g.row0 * dt * 2 : nullptr, g.nseq, g.L, dt, 1, n,
+                               G + m->off[P_CTX], false, true, unscale, s2));
     return MUDPT_OK;
 }
 
@@ -1337,6 +1486,8 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
     if (!strcmp(name, "attn_two_kernels")) { m->attn_two_kernels = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "attn_fused_w1")) { m->attn_fused_w1 = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "last_single")) { m->last_single = value != 0; return MUDPT_OK; }
+    if (!strcmp(name, "txt_bucket_cost")) { m->txt_bucket_cost = value > 0 ? value : 0; m->prompts_set = false; return MUDPT_OK; }
+    if (!strcmp(name, "txt_buckets")) { m->txt_buckets = value > 1 ? value : 1; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
     if (!strcmp(name, "prof_stride")) { m->prof_stride = value > 1 ? value : 1; return MUDPT_OK; }
     if (!strcmp(name, "cocoop_chunk")) { m->cocoop_chunk = value; m->prompts_set = false; return MUDPT_OK; }  // likewise
     if (!strcmp(name, "txt_split")) {  // the [W | W] copies are made while the weights are ingested: decide before the first mudpt_set_weight
@@ -1394,6 +1545,7 @@ extern "C" int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch,
     const float* src = nullptr;
     size_t n = 0;
     auto tower = [&](Tower& t, const std::string& rest, int nseq) {
+        if (!t.segs.empty() && rest != "x_out") return;  // packed in length buckets: no [seq, L, d] view (set txt_buckets = 1 to tap)
         n = (size_t)nseq * t.L * t.d;
         if (rest == "x_out") { src = t.xout_sel; n = (size_t)nseq * t.d; }  // the used row (CLS / EOT) of every sequence only
         else if (rest.rfind("x_in.", 0) == 0) {

@@ -155,6 +155,12 @@ class CustomCLIP(nn.Module):
         (before the weights / class prompts are ingested)."""
         capi.check(self.lib.mudpt_model_set(self._h, name.encode(), int(value)), f"model_set({name})")
 
+    def text_layout(self):
+        """(token rows, length buckets, longest kept length) of one text-tower pass (``mudpt_text_layout``)."""
+        r, b, l = C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(self.lib.mudpt_text_layout(self._h, C.byref(r), C.byref(b), C.byref(l)), "text_layout")
+        return r.value, b.value, l.value
+
     def set_params(self, tensors: Dict[str, torch.Tensor]):
         self._text_version = None
         with torch.no_grad():

@@ -60,8 +60,9 @@ def case208():
 def test_c208_logits_loss_grads_match_reference(case208, dtype):
     case = case208
     m = build(case.cfg, case.frozen, case.tokens, case.params, dtype, len(case.labels))
-    Le = m.debug_read("txt.x_in.0", 2).numel() // (208 * case.cfg.t_width)
+    rows, buckets, Le = m.text_layout()
     assert Le == int(case.eot.max()) + 1 and Le >= 17  # the trimmed text tower runs well past the 9 positions of the 11-class cases
+    assert buckets > 1 and rows < 208 * Le  # and in length buckets: this test pins the bucketed tower to the reference's numbers
     loss, logits = m.forward_backward(case.images, case.labels, return_logits=True)
     torch.cuda.synchronize()
     d = logits.cpu() - case.logits
@@ -96,6 +97,31 @@ def test_c208_text_tower_trim_changes_nothing(case208):
     for k, g in out[0][2].items():
         scale = g.pow(2).mean().sqrt().item()
         torch.testing.assert_close(out[1][2][k], g, atol=2e-4 * scale + 1e-12, rtol=0, msg=k)
+
+
+def test_c208_length_buckets_change_nothing(case208):
+    """The class prompts sorted by length and run in 2-4 buckets, each to its own longest EOT, against the single-bucket run (every prompt to
+    position 25): sequences are independent in every kernel of the tower, so the text features -- hence the logits and the loss -- are
+    BIT-identical; the gradients differ by the order of the fp32 sums over classes only."""
+    case, out, rows = case208, {}, {}
+    for nb in (1, 2, 3, 4):
+        # txt_bucket_cost 0: cut wherever it saves a row (the default charges 1024 rows per extra bucket and stops at 2 here)
+        m = build(case.cfg, case.frozen, case.tokens, case.params, "fp16", 2, knobs={"txt_buckets": nb, "txt_bucket_cost": 0})
+        rows[nb] = m.text_layout()
+        loss, logits = m.forward_backward(case.images, case.labels, return_logits=True)
+        torch.cuda.synchronize()
+        out[nb] = (logits.cpu(), loss.item(), {k: g.detach().cpu().clone() for k, g in m.grads().items()})
+        m.eval()
+        assert torch.equal(m(case.images).cpu(), out[nb][0])
+        m.close()
+    print("text layouts (rows, buckets, longest):", rows)
+    assert rows[1][1] == 1 and rows[1][0] == 208 * rows[1][2]
+    assert all(rows[nb][1] == nb for nb in (2, 3, 4)) and rows[4][0] < rows[3][0] < rows[2][0] < 0.8 * rows[1][0]
+    for nb in (2, 3, 4):
+        assert torch.equal(out[nb][0], out[1][0]) and out[nb][1] == out[1][1], nb
+        for k, g in out[1][2].items():
+            scale = g.pow(2).mean().sqrt().item()
+            assert (out[nb][2][k] - g).abs().max().item() <= 2e-5 * scale + 1e-12, (nb, k)
 
 
 # ---- 1000 classes against the oracle -----------------------------------------------------------------------------------------
