@@ -229,3 +229,33 @@ def test_last_block_single_query_path_equals_the_general_kernels(dtype):
     for k, g in out[0][2].items():
         rms = g.pow(2).mean().sqrt().item()
         assert (out[1][2][k] - g).pow(2).mean().sqrt().item() <= {"fp16": 5e-3, "bf16": 6e-2}[dtype] * rms + 1e-12, k
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_training_trajectory_tracks_the_oracle(dtype):
+    """Six momentum-SGD steps (forward, cross-entropy, backward, the library's SGD: trainers/mudpt.py:249-251 with Dassl's optimizer
+    defaults) on the tiny shape with a learning rate large enough to move the loss, against the CPU oracle taking the same six steps
+    from the same start: the loss sequences agree step by step and the parameters stay together (errors do not compound beyond the
+    per-step gradient noise)."""
+    case = GoldenCase("mudpt_tiny")
+    lr, steps = 0.05, 6
+    m = build(case, dtype)
+    flat = O.flatten(case.params).clone()
+    buf, ref_losses, got_losses = None, [], []
+    for _ in range(steps):
+        loss, _, grads = O.forward_backward(case.cfg, case.frozen, O.unflatten(flat, case.cfg), case.class_embedding, case.eot, case.images, case.labels)
+        ref_losses.append(loss.item())
+        flat, buf = O.sgd_step(flat, O.flatten(grads), buf, lr)
+        got_losses.append(m.forward_backward(case.images, case.labels).item())
+        m.sgd_step(lr, momentum=0.9, weight_decay=5e-4)
+    torch.cuda.synchronize()
+    print(f"{dtype} losses: oracle {['%.4f' % v for v in ref_losses]}  library {['%.4f' % v for v in got_losses]}")
+    assert ref_losses[-1] < ref_losses[0] - 0.05, "the trajectory must actually train"
+    tol = {"fp16": 2e-3, "bf16": 3e-2}[dtype]
+    for a, b in zip(ref_losses, got_losses):
+        assert abs(a - b) <= tol * max(1.0, abs(a)), (ref_losses, got_losses)
+    moved = (flat - O.flatten(case.params)).pow(2).mean().sqrt().item()
+    err = (m.flat_params.cpu() - flat).pow(2).mean().sqrt().item()
+    print(f"{dtype}: parameters moved {moved:.3e} rms, library - oracle {err:.3e} rms")
+    assert err <= {"fp16": 2e-2, "bf16": 1.5e-1}[dtype] * moved
+    m.close()
