@@ -75,6 +75,10 @@ struct LnBwdArgs {
     int rows = 0, d = 0;
     bool by_token = false;  // dy / mean / rstd rows are indexed by the token row (row_index[r]) instead of r
     bool stats_by_token = false;  // only mean / rstd are indexed by the token row; dy stays compact (row r)
+    // Backward of the prompt splice, fused (identity row map only): result rows whose position inside their sequence (r % side_L) lies in
+    // [side_row0, side_row0 + side_n) go, in fp32, to side[(r / side_L) * side_ldb + (pos - side_row0) * d] instead -- the gradient of
+    // the spliced-in prompt row -- and ZERO is written to dx / dx_lp: the rows the splice overwrote receive no gradient (clip/model.py:281-297).
+    float* side = nullptr; int side_row0 = 0, side_n = 0, side_L = 1; size_t side_ldb = 0;
 };
 int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);
 

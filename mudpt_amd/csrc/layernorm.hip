@@ -90,6 +90,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     const size_t sr = p.by_token ? t : (size_t)r;  // row of dy
     const size_t st = (p.by_token || p.stats_by_token) ? t : (size_t)r;  // row of the statistics
     const float mean = p.mean[st], rstd = p.rstd[st];
+    f32x4* side_row = nullptr;  // wave-uniform: this row is a spliced prompt position
+    if (p.side) {
+        const int pos = (int)(t % (size_t)p.side_L) - p.side_row0;
+        if (pos >= 0 && pos < p.side_n) side_row = (f32x4*)(p.side + (t / (size_t)p.side_L) * p.side_ldb + (size_t)pos * p.d);
+    }
     f32x4 xh[LN_MAXV], g[LN_MAXV];
     typename T::vec4 rv[LN_MAXV];  // the T residual gradient, fetched with the other operands so its latency hides behind the reduction
     float s1 = 0.f, s2 = 0.f;
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
             if (p.dres_lp) {  // the gradient stream itself is kept in T (bf16 mode): no fp32 copy to read or write
                 dx += f32x4{(float)rv[k][0], (float)rv[k][1], (float)rv[k][2], (float)rv[k][3]};
             }
+            if (side_row) { side_row[i] = dx; dx = f32x4{0.f, 0.f, 0.f, 0.f}; }
             if (p.dx) ((f32x4*)(p.dx + t * p.lddx))[i] = dx;
             if (p.dx_lp) {
                 typename T::vec4 o = {(elem)dx[0], (elem)dx[1], (elem)dx[2], (elem)dx[3]};
@@ -161,6 +167,7 @@ int launch_ln_fwd(int dtype, const LnFwdArgs& a, hipStream_t s, const LaunchProf
 int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s, const LaunchProf* prof) {
     ARG_CHECK(a.dy && a.x && a.mean && a.rstd && a.gamma && (a.dx || a.dx_lp), "ln_bwd: null operand");
     ARG_CHECK(!(a.dres && a.dres_lp), "ln_bwd: dres and dres_lp are exclusive");
+    ARG_CHECK(!a.side || (!a.row_index && a.side_L > 0 && a.side_n > 0), "ln_bwd: the fused splice backward needs the identity row map");
     ARG_CHECK(a.rows > 0 && a.d > 0 && a.d % 4 == 0 && a.d <= 256 * LN_MAXV, "ln_bwd: bad shape rows=%d d=%d", a.rows, a.d);
     ARG_CHECK(a.ldx % 4 == 0 && a.lddy % 4 == 0 && a.lddx % 4 == 0, "ln_bwd: strides must be multiples of 4");
     const dim3 grid((a.rows + 3) / 4), block(256);

@@ -152,6 +152,7 @@ struct mudpt_model {
     // prompt learner intermediates (fp32)
     float *shared = nullptr, *t2v = nullptr, *v2t = nullptr, *vis_deep = nullptr, *txt_deep = nullptr;
     float *d_vis_deep = nullptr, *d_txt_deep = nullptr, *d_vprompt0 = nullptr;
+    float* vsplice = nullptr;  // [max_batch][(depth - 1) n_ctx][dv] fp32: per-image gradients of the spliced vision prompt rows (vision_backward)
     // head
     float *img_f = nullptr, *txt_f = nullptr, *img_n = nullptr, *txt_n = nullptr, *img_inv = nullptr, *txt_inv = nullptr;
     float *logits = nullptr, *dlogits = nullptr, *row_loss = nullptr, *dimg = nullptr, *dtxt = nullptr, *loss = nullptr;
@@ -440,6 +441,7 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
         const size_t dn = (size_t)(D1 > 0 ? D1 : 1) * n;
         ALLOC(m->shared, (size_t)n * dv * 4); ALLOC(m->t2v, dn * dv * 4); ALLOC(m->v2t, dn * e * 4);
         ALLOC(m->vis_deep, dn * dv * 4); ALLOC(m->txt_deep, dn * dt * 4);
+        ALLOC(m->vsplice, (size_t)B * dn * dv * 4);
         ALLOC(m->d_vis_deep, dn * dv * 4); ALLOC(m->d_txt_deep, dn * dt * 4); ALLOC(m->d_vprompt0, (size_t)n * dv * 4);
         ALLOC(m->img_f, (size_t)B * e * 4); ALLOC(m->txt_f, (size_t)TS * e * 4); ALLOC(m->img_n, (size_t)B * e * 4); ALLOC(m->txt_n, (size_t)TS * e * 4);
         ALLOC(m->img_inv, B * 4); ALLOC(m->txt_inv, TS * 4);
@@ -970,7 +972,9 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
 }
 
 // in: t.dx / t.dx_lp = gradient w.r.t. the block output; out: the same buffers = gradient w.r.t. x_in
-static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
+// side != null: block i's input had deep-prompt rows spliced in; their gradient goes to side[seq][n_ctx][d] (row stride side_ldb per
+// sequence) and the stream gets zeros on those rows (LnBwdArgs::side)
+static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s, float* side = nullptr, size_t side_ldb = 0) {
     const int M = tower_rows(t, nseq), d = t.d, dt = m->dtype;
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
@@ -1011,6 +1015,7 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s) {
     LnBwdArgs b1; b1.dy = t.h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.lddres = d;
     if (m->lp_grad) b1.dres_lp = t.dx_lp; else { b1.dres = t.dx; b1.dx = t.dx; }
     b1.lddx = d; b1.dx_lp = t.dx_lp; b1.lddx_lp = d; b1.rows = M; b1.d = d;
+    if (side) { b1.side = side; b1.side_row0 = t.prompt_row0; b1.side_n = m->cfg.n_ctx; b1.side_L = t.L; b1.side_ldb = side_ldb; }
     TRY(ln_bwd_call(m, t, b1, s));
     return MUDPT_OK;
 }
@@ -1300,10 +1305,26 @@ static int vision_backward(mudpt_model* m, int B, float unscale, hipStream_t s) 
     LnBwdArgs bq; bq.dy = m->df_ln; bq.lddy = dv; bq.dy_f32 = true; bq.x = V.xout_sel; bq.ldx = dv; bq.mean = m->post_mean; bq.rstd = m->post_rstd;
     bq.gamma = m->ln_post_g; bq.dx = m->lp_grad ? nullptr : V.dsel; bq.lddx = dv; bq.dx_lp = V.dsel_lp; bq.lddx_lp = dv; bq.rows = B; bq.d = dv;
     TRY(launch_ln_bwd(m->dtype, bq, s));
+    // Backward of the splice: the prompt rows of d(x_in[i]) feed d(vis_deep[i-1]) and the rows the splice overwrote get no gradient.
+    // ln_1's backward writes those rows, in fp32, to vsplice[b][(i - 1) n + k][:] and zeros to the stream (LnBwdArgs::side); ONE
+    // fixed-order reduction over the images after the last block replaces a reduce-and-zero launch per block on the critical path.
+    const int used = (V.layers - 1 < D1 ? V.layers - 1 : D1) * n;  // layers >= depth never consume a prompt
+    const size_t side_ldb = (size_t)used * dv;
     for (int i = V.layers - 1; i >= 0; --i) {
-        if (i == V.layers - 1) TRY(block_bwd_tail(m, V, B, s)); else TRY(block_bwd(m, V, i, B, s));
-        if (i >= 1 && i - 1 < D1)  // backward of the splice: prompt rows feed d(vis_deep[i-1]); the overwritten rows get no gradient
-            TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : V.dx, V.dx_lp, B, Lv, dv, Lv - n, n, m->d_vis_deep + (size_t)(i - 1) * n * dv, true, false, unscale, s));
+        const bool spliced = i >= 1 && i - 1 < D1;
+        if (i == V.layers - 1) {
+            TRY(block_bwd_tail(m, V, B, s));
+            if (spliced) {  // the tail's ln_1 backward is not fused: take the rows from the stream
+                TRY(launch_reduce_rows(m->dtype, m->lp_grad ? nullptr : V.dx, V.dx_lp, B, Lv, dv, Lv - n, n, m->d_vis_deep + (size_t)(i - 1) * n * dv, true, false, unscale, s));
+            }
+        } else {
+            TRY(block_bwd(m, V, i, B, s, spliced ? m->vsplice + (size_t)(i - 1) * n * dv : nullptr, side_ldb));
+        }
+    }
+    {
+        // blocks 1 .. layers-2 (the fused ones): rows 0 .. n (layers - 2) of every image's side block
+        const int fused = (V.layers - 2 < D1 ? V.layers - 2 : D1) * n;
+        if (fused > 0) TRY(launch_reduce_rows(m->dtype, m->vsplice, nullptr, B, used, dv, 0, fused, m->d_vis_deep, false, false, unscale, s));
     }
     // ln_pre backward on the prompt rows only (patch / CLS rows have no trainable ancestor), in place
     LnBwdArgs bp; bp.dy = m->lp_grad ? (const void*)V.dx_lp : (const void*)V.dx; bp.lddy = dv; bp.dy_f32 = !m->lp_grad; bp.x = m->xpre; bp.ldx = dv; bp.row_index = m->vprompt_rows; bp.mean = m->pre_mean; bp.rstd = m->pre_rstd;
