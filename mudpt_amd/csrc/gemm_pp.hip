@@ -39,7 +39,8 @@ __device__ inline void vmcnt() {
 // ST / LD: cache policy of the epilogue's output stores / of EPI_GELU_BWD's one-touch aux read (aux bits of the buffer instructions on
 // gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Measured in round 2 (tools/gemm_bench.py, A/B in one process, B = 256 shapes): write-through
 // sc1 / sc0 sc1 stores are 8-60 % SLOWER (fc 315 -> 515 us: the L2 no longer absorbs the store bursts), nt stores and nt aux loads
-// are within +-1 % over the 8 GEMMs of a block.  Plain policy everywhere; the parameters stay for the next experiment.
+// are within +-1 % over the 8 GEMMs of a block.  Counters with nt stores over the whole step (round 2, separate --pmc passes): fc's HBM-side reads 412 -> 332 MB per launch, but its
+// writes 632 -> 900 MB (partial lines are no longer combined in the L2) and the step 25.10 -> 25.38 ms.  Plain policy everywhere; the parameters stay for the next experiment.
 template <typename T, int EPI, int ST = 0, int LD = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int ntiles, int rem_half) {
     using elem = typename T::elem;
