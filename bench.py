@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--no-last-single", action="store_true", help="last block through the general attention kernels on all rows (A/B of the single-query path)")
     ap.add_argument("--class-parallel", action="store_true", help="N > 1: each rank encodes C / N class prompts (two extra [C, embed] sums per step); "
                     "meant for --classes 1000 (BASELINE configs[2])")
+    ap.add_argument("--no-attn-window", action="store_true", help="block 0's attention backward on all rows (A/B of the prompt-row window form)")
     ap.add_argument("--txt-buckets", type=int, default=0, help="maximum number of length buckets of the class prompts (0 = library default 3; 1 = none)")
     ap.add_argument("--fp32-streams", action="store_true", help="keep the update / gradient streams in fp32 (A/B of the bf16 streams)")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a captured hipGraph (implies --no-profile)")
@@ -121,6 +122,8 @@ def main():
         knobs["attn_two_kernels"] = 1
     if args.txt_buckets:
         knobs["txt_buckets"] = args.txt_buckets
+    if args.no_attn_window:
+        knobs["attn_window"] = 0
     if args.no_last_single:
         knobs["last_single"] = 0
     shape = ModelShape()  # CLIP ViT-B/16, n_ctx 4, depth 12

@@ -154,7 +154,8 @@ int mudpt_sgd_reset(mudpt_model* m);
 int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* host_out, size_t capacity, size_t* numel);
 
 /* Per-handle tuning knobs for A/B measurements in one process (tools/gemm_bench.py, tests); nothing is process-global, so two
- * models in one process do not interfere: "gemm_variant"; "last_single" (0 = the last block's attention on all rows instead of the
+ * models in one process do not interfere: "gemm_variant"; "attn_window" (0 = block 0's attention backward on all rows instead of the prompt rows' blocks);
+ * "last_single" (0 = the last block's attention on all rows instead of the
  * single-query form); "attn_two_kernels" (1 = attention backward as two kernels); "cocoop_chunk"
  * (cap on the images per CoCoOp text-tower pass; read by the next mudpt_set_class_prompts); "lp_grad" (bf16 mode: 0 keeps the gradient / update streams in fp32);
  * "txt_buckets" (maximum number of length buckets
@@ -199,7 +200,10 @@ int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, i
 /* causal: bit 0 = causal mask.  Kernel choice (tests / A-B).  Default: padded length <= 96 (the text tower): the fused two-sweep pass over
  * resident Q, K, V, dO; longer non-causal sequences up to 224 (the vision tower): the single-sweep kernel (S, dP, exp computed once, dS
  * crosses LDS for dQ); otherwise the dQ kernel + dK/dV kernel pair (delta through `delta`).  bit 1 = force the two kernels, bit 3 = force the
- * fused two-sweep pass, bit 2 = the same with two 16-row blocks per wave, bit 4 = force the single sweep (non-causal, L <= 224). */
+ * fused two-sweep pass, bit 2 = the same with two 16-row blocks per wave, bit 4 = force the single sweep (non-causal, L <= 224).
+ * Window form (block 0 of a tower needs its input gradient on the prompt rows only): bits 20-27 = n > 0 wanted rows per sequence starting
+ * at row bits 8-19.  The 16-row blocks (L > 224: 64-row groups) holding a wanted row are computed exactly as without the window; all other
+ * rows of dqkv are left unwritten. */
 int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                         float* delta, void* dqkv, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream);
 /* Single-query attention of a tower's LAST block (only the CLS / EOT row of its output is used, clip/model.py:549, trainers/mudpt.py:154):

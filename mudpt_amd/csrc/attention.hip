@@ -378,6 +378,8 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
         delta = group_sum(delta);
         const size_t stat = ((size_t)b * p.H + hd) * Lp + q;
         if (g == 0) p.delta[stat] = delta;
+        // window form: delta of EVERY query (the dK / dV pass sums over all of them), dQ only for the blocks that hold a wanted row
+        if (p.win_n > 0 && (qb * 16 >= p.win_row0 + p.win_n || qb * 16 + 16 <= p.win_row0)) return;
         const float nlse = -lse_q * LOG2E;
         const int nkc = CAUSAL ? (qb >> 1) + 1 : NC;
 
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int qc_sel = p.sel_rows ? (p.sel_rows[b] - b * L) >> 5 : -1;  // dO is zero outside this 32-query chunk
     auto block = [&](int kb, const Frags& f) {
         const int key = kb * 16 + c;
+        if (p.win_n > 0 && (kb * 16 >= p.win_row0 + p.win_n || kb * 16 + 16 <= p.win_row0)) return;  // window form: no wanted key row in this block
         const vec8 k0 = f.k0, k1 = f.k1, v0 = f.v0, v1 = f.v1;
         f32x4 dK[4], dV[4];
 #pragma unroll
@@ -1012,6 +1015,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(AttnArgs p, cons
     delta = group_sum(delta);
     const size_t stat = (size_t)pair * Lp + (q < Lp ? q : 0);
     if (g == 0 && q < Lp) p.delta[stat] = delta;
+    // window form (uniform per wave): delta of every query, dQ only for the 16-row blocks that hold a wanted row; a wave that leaves
+    // skips the barriers below, so the decision is made per WORKGROUP (its 64 queries)
+    if (p.win_n > 0 && (sb * 64 >= p.win_row0 + p.win_n || sb * 64 + 64 <= p.win_row0)) return;
     const float nlse = q < L ? -p.lse[stat] * LOG2E : 0.f;
     f32x4 dQ[4];
 #pragma unroll
@@ -1064,6 +1070,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_tiled_kernel(AttnArgs p, int
     const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
     const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
     const int key = sb * 64 + wave * 16 + c;
+    if (p.win_n > 0 && (sb * 64 >= p.win_row0 + p.win_n || sb * 64 + 64 <= p.win_row0)) return;  // window form: no wanted key in this workgroup's 64
     const vec8 k0 = A::grow(base + HD, ld, key, L, 0, lane), k1 = A::grow(base + HD, ld, key, L, 1, lane);
     const vec8 v0 = A::grow(base + 2 * HD, ld, key, L, 0, lane), v1 = A::grow(base + 2 * HD, ld, key, L, 1, lane);
     f32x4 dK[4], dV[4];
@@ -1252,6 +1259,7 @@ static int dispatch(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
     const int nc = attn_padded_len(a.L) / 32;
 #define MUDPT_ATTN_CASE(N)                                                                     \
     case N:                                                                                    \
+        if (BWD && a.win_n > 0 && !a.sel_rows) return a.causal ? bwd_cfg<T, N, true>(a, s, prof) : bwd_cfg<T, N, false>(a, s, prof); /* window: two kernels */ \
         if (BWD && !a.sel_rows && !a.causal && !a.two_kernels && !a.force_fused && (N >= 4 || a.sweep)) return bwd_sweep_cfg<T, N>(a, s, prof); \
         if (BWD && !a.sel_rows && !a.two_kernels && (N <= 3 || a.force_fused)) {                   \
             if (a.fused_w1) return a.causal ? bwd_fused_cfg<T, N, true, 1>(a, s, prof) : bwd_fused_cfg<T, N, false, 1>(a, s, prof); \

@@ -101,6 +101,11 @@ struct AttnArgs {
     bool force_fused = false;   // bwd: the fused single pass also where the dispatcher prefers the two kernels (NC > 3; A/B, tests)
     bool fused_w1 = false;      // bwd, fused form: NC waves with two 16-row blocks each instead of 2 NC waves with one (A/B)
     bool two_kernels = false;   // bwd: the dQ kernel + dK/dV kernel pair instead of the fused single pass (A/B runs, tests)
+    // bwd, optional: only the dqkv rows win_row0 .. win_row0 + win_n - 1 of every sequence are wanted (block 0 of a tower: its input
+    // gradient is needed on the prompt rows only).  The 16-row blocks that hold such a row are computed in full -- dQ from all keys,
+    // dK / dV from all queries, same sums in the same order as without the window -- and every other row of dqkv is left UNWRITTEN.
+    // Honoured by the two-kernel form (whole sequence on chip, non-causal) and the tiled kernels; elsewhere everything is computed.
+    int win_row0 = 0, win_n = 0;
     int B = 0, L = 0, H = 0; bool causal = false;
 };
 // Single-query forms for the last block (attention_single.hip): ONE query row per sequence (token row a.sel_rows[b]) against all keys

@@ -183,6 +183,7 @@ struct mudpt_model {
     int txt_bucket_cost = 1024;  // knob: what one more bucket costs in the cut search, in token rows (its extra launches per block)
     int txt_buckets = 3;   // knob: at most this many length buckets for the class prompts (1 = every prompt runs to the longest EOT)
     bool attn_fused_w1 = false;
+    bool attn_window = true;  // knob: block 0's attention backward computes the 16-row blocks of the prompt rows only (0 = all rows)
     bool last_single = true;  // knob: single-query attention in the last block (0 = the general kernels on all rows)
     bool attn_two_kernels = false;  // knob: attention backward as the dQ + dK/dV kernel pair instead of the fused single pass
     int cocoop_chunk = 0;  // knob: cap on the images per text-tower pass (0 = as many as the memory budget allows)
@@ -994,6 +995,8 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s, f
         at.dout = (const char*)t.dattn + (size_t)g.row0 * d * esz; at.dqkv = (char*)t.dqkv + (size_t)g.row0 * 3 * d * esz; at.delta = t.delta + g.lse0;
         at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
         if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
+        // block 0: only the prompt rows of dqkv are read below (Tower::head_rows)
+        if (i == 0 && t.head_rows && t.layers > 1 && m->attn_window) { at.win_row0 = t.prompt_row0; at.win_n = t.head_n; }
         TRY(attn_call(m, t, at, true, s));
     }
     if (i == 0 && t.head_rows && t.layers > 1) {
@@ -1506,6 +1509,7 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
     if (!strcmp(name, "txt_trim")) { m->txt_trim = value != 0; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
     if (!strcmp(name, "attn_two_kernels")) { m->attn_two_kernels = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "attn_fused_w1")) { m->attn_fused_w1 = value != 0; return MUDPT_OK; }
+    if (!strcmp(name, "attn_window")) { m->attn_window = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "last_single")) { m->last_single = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "txt_bucket_cost")) { m->txt_bucket_cost = value > 0 ? value : 0; m->prompts_set = false; return MUDPT_OK; }
     if (!strcmp(name, "txt_buckets")) { m->txt_buckets = value > 1 ? value : 1; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
@@ -1670,5 +1674,6 @@ extern "C" int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* o
                                    int32_t L, int32_t H, int32_t causal, void* stream) {
     AttnArgs a; a.qkv = qkv; a.out = (void*)out; a.dout = dout; a.lse = (float*)lse; a.delta = delta; a.dqkv = dqkv; a.B = B; a.L = L; a.H = H;
     a.causal = (causal & 1) != 0; a.two_kernels = (causal & 2) != 0; a.fused_w1 = (causal & 4) != 0; a.force_fused = (causal & 12) != 0; a.sweep = (causal & 16) != 0;
+    a.win_n = (causal >> 20) & 0xff; a.win_row0 = (causal >> 8) & 0xfff;  // bits 8-19: first wanted row, bits 20-27: number of wanted rows (0 = all)
     return launch_attn_bwd(dtype, a, (hipStream_t)stream);
 }

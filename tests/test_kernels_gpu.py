@@ -456,6 +456,37 @@ def test_attention_single_query(lib, dtype, B, L, H, causal):
     assert torch.equal(again[..., H * 64:], dqkv[..., H * 64:]) and torch.equal(dq2, dq_sel)
 
 
+@pytest.mark.parametrize("B,L,H,causal,row0,n", [(3, 201, 12, False, 197, 4), (2, 77, 8, True, 1, 4), (3, 150, 2, False, 14, 4), (2, 581, 4, False, 577, 4),
+                                                 (2, 581, 2, False, 62, 5), (4, 26, 8, True, 1, 16)])
+def test_attention_backward_window_form(lib, B, L, H, causal, row0, n):
+    """Block 0 of a tower needs d(qkv) on the prompt rows only: the window form computes the 16-row blocks (L > 224: 64-row groups) that hold
+    rows row0 .. row0 + n - 1 of every sequence -- dQ from all keys, dK / dV from all queries -- and leaves the other rows unwritten.  The
+    wanted rows equal the two-kernel form's bit for bit (same sums, same order); the rest of the buffer keeps its previous contents outside
+    the computed blocks."""
+    dt, tt = DT["bf16"]
+    g = torch.Generator().manual_seed(L * 7 + row0)
+    qkv = torch.randn(B, L, 3 * H * 64, generator=g).to(tt).cuda()
+    dout = torch.randn(B, L, H * 64, generator=g).to(tt).cuda()
+    Lp = lib.mudpt_attention_padded_len(L)
+    out, lse, delta = torch.empty(B, L, H * 64, device="cuda", dtype=tt), torch.zeros(B, H, Lp, device="cuda"), torch.zeros(B, H, Lp, device="cuda")
+    ok(lib, lib.mudpt_attention_fwd(dt, P(qkv), P(out), P(lse), B, L, H, int(causal), None))
+    full = torch.empty_like(qkv)
+    ok(lib, lib.mudpt_attention_bwd(dt, P(qkv), P(out), P(dout), P(lse), P(delta), P(full), B, L, H, int(causal) | 2, None))
+    torch.cuda.synchronize()
+    delta_full = delta.clone()
+    win = torch.full_like(qkv, 3.0)
+    delta.zero_()
+    ok(lib, lib.mudpt_attention_bwd(dt, P(qkv), P(out), P(dout), P(lse), P(delta), P(win), B, L, H, int(causal) | (row0 << 8) | (n << 20), None))
+    torch.cuda.synchronize()
+    assert torch.equal(win[:, row0:row0 + n], full[:, row0:row0 + n])
+    assert torch.equal(delta[..., :L], delta_full[..., :L])  # delta of every query feeds the dK / dV pass
+    gran = 64 if L > 224 else 16
+    lo, hi = row0 // gran * gran, min(L, -(-(row0 + n) // gran) * gran)
+    untouched = torch.ones(L, dtype=torch.bool)
+    untouched[lo:hi] = False
+    assert (win[:, untouched] == 3.0).all(), "rows outside the window's blocks must not be written"
+
+
 def test_attention_softmax_extremes(lib):
     """Large score spread: one key dominates a row (exp underflow for the rest) -- no NaN, matches the oracle."""
     B, L, H = 1, 201, 1
