@@ -91,7 +91,7 @@ def main():
                     "meant for --classes 1000 (BASELINE configs[2])")
     ap.add_argument("--no-attn-window", action="store_true", help="block 0's attention backward on all rows (A/B of the prompt-row window form)")
     ap.add_argument("--txt-buckets", type=int, default=0, help="maximum number of length buckets of the class prompts (0 = library default 3; 1 = none)")
-    ap.add_argument("--fp32-streams", action="store_true", help="keep the update / gradient streams in fp32 (A/B of the bf16 streams)")
+    ap.add_argument("--fp32-streams", action="store_true", help="keep the gradient stream (and in bf16 mode the update stream) in fp32 (A/B of the T streams)")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a captured hipGraph (implies --no-profile)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the short fp16 (parity configuration) timing appended to the bf16 line")
     args = ap.parse_args()
@@ -216,7 +216,7 @@ def main():
     model.close()
     del model
 
-    # the parity configuration (fp16 operands, fp32 residual / update / gradient streams, split text-tower operands: logits within 1e-3 of
+    # the parity configuration (fp16 operands, fp32 residual and update streams, fp16 activation gradients, split text-tower operands: logits within 1e-3 of
     # the reference) timed on the same box right after the bf16 headline, so the driver's record carries both
     parity_ms = None
     if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_parity_mode and not args.graph:
@@ -288,7 +288,7 @@ def main():
                                "hbm_kernels": hbm, "hbm_kernels_steps": hbm_steps}
         if parity_ms is not None:
             out["parity_mode_ms_per_step"] = round(parity_ms, 3)
-            out["parity_mode"] = "dtype fp16: fp16 MFMA operands, fp32 residual / update / gradient streams, split text-tower operands (logits within 1e-3 of the reference: tests/test_model_gpu.py)"
+            out["parity_mode"] = "dtype fp16: fp16 MFMA operands, fp32 residual / update streams, fp16 activation gradients under a static loss scale, split text-tower operands (logits within 1e-3 of the reference: tests/test_model_gpu.py)"
         if collective is not None:
             out["collective"] = collective
         if world == 1 and not args.no_cpu_baseline:
