@@ -216,7 +216,7 @@ def main():
     model.close()
     del model
 
-    # the parity configuration (fp16 operands, fp32 residual and update streams, fp16 activation gradients, split text-tower operands: logits within 1e-3 of
+    # the parity configuration (fp16 operands, fp32 residual / update / gradient streams, split text-tower operands: logits within 1e-3 of
     # the reference) timed on the same box right after the bf16 headline, so the driver's record carries both
     parity_ms = None
     if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_parity_mode and not args.graph:
@@ -288,7 +288,7 @@ def main():
                                "hbm_kernels": hbm, "hbm_kernels_steps": hbm_steps}
         if parity_ms is not None:
             out["parity_mode_ms_per_step"] = round(parity_ms, 3)
-            out["parity_mode"] = "dtype fp16: fp16 MFMA operands, fp32 residual / update streams, fp16 activation gradients under a static loss scale, split text-tower operands (logits within 1e-3 of the reference: tests/test_model_gpu.py)"
+            out["parity_mode"] = "dtype fp16: fp16 MFMA operands, fp32 residual / update / gradient streams, split text-tower operands (logits within 1e-3 of the reference: tests/test_model_gpu.py)"
         if collective is not None:
             out["collective"] = collective
         if world == 1 and not args.no_cpu_baseline:

@@ -157,7 +157,8 @@ int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* hos
  * models in one process do not interfere: "gemm_variant"; "attn_window" (0 = block 0's attention backward on all rows instead of the prompt rows' blocks);
  * "last_single" (0 = the last block's attention on all rows instead of the
  * single-query form); "attn_two_kernels" (1 = attention backward as two kernels); "cocoop_chunk"
- * (cap on the images per CoCoOp text-tower pass; read by the next mudpt_set_class_prompts); "lp_grad" (0 keeps the gradient stream of the residual in fp32 -- and, in bf16 mode, the forward's update stream too);
+ * (cap on the images per CoCoOp text-tower pass; read by the next mudpt_set_class_prompts); "lp_grad" (gradient stream of the residual in T: default in bf16 mode, where 0 also returns the forward's update stream to fp32;
+ * 1 in fp16 mode trades 30 % more gradient error for 0.9 ms);
  * "lp_upd" (the forward's update stream in T: default in bf16 mode, off in fp16 mode where it would cost 2e-4 of logit error);
  * "txt_buckets" (maximum number of length buckets
  * of the class prompts, 1 = none) and "txt_bucket_cost" (token rows one more bucket must save, default 1024; both read by the next

@@ -195,51 +195,62 @@ int launch_reduce_rows(int dtype, float* src, void* src_lp, int B, int L, int d,
     return MUDPT_OK;
 }
 
-// ---- small fp32 GEMM: C = alpha * op(A) op(B) + bias + beta * C, 16x16 output tiles, 64-deep K chunks through LDS
-// (the prompt projections: M = 4..44 rows; each workgroup is a latency chain over K, so the chunk is deep: 4 loads per operand
-// per thread in flight and one barrier pair per 64 k instead of per 16)
-__global__ __launch_bounds__(256) void sgemm_kernel(bool tA, bool tB, int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
-                                                    const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
-                                                    const float* __restrict__ bias) {
-    constexpr int KC = 64;
-    __shared__ float As[16][KC + 1], Bs[KC][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+// ---- small fp32 GEMM: C = alpha * op(A) op(B) + bias + beta * C (the prompt projections, M = 4..44 rows; the feature projections)
+// One workgroup per 16 x 16 output tile, and the tile is a LATENCY chain over K (a few global round trips), not a throughput problem:
+// the 8 waves split K between them, each wave feeds v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate) straight from global
+// memory -- lane (r, g) supplies A[m0 + r][k] and B[k][n0 + r] for k = k0 + 4 g + u, any partition of k works as long as A and B agree --
+// with all of its loads of up to 96 k in flight before the first MFMA, and the 8 partial tiles are summed through LDS in wave order
+// (fixed order: bitwise reproducible).  K = 768: one round trip of 24 loads per lane instead of 12 dependent chunk round trips.
+constexpr int SG_WAVES = 8, SG_STEPS = 6;  // waves per tile; 16-k steps whose loads travel together
+__global__ __launch_bounds__(SG_WAVES * 64) void sgemm_kernel(bool tA, bool tB, int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
+                                                              const float* __restrict__ B, int ldb, float beta, float* __restrict__ C, int ldc,
+                                                              const float* __restrict__ bias) {
+    __shared__ float part[SG_WAVES][16][17];
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
-    const int m = m0 + ty, n = n0 + tx;
-    float acc = 0.f;
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        float av[4], bv[4];
+    const int per = ((K + SG_WAVES - 1) / SG_WAVES + 15) & ~15;  // k per wave, a multiple of the 16-k step
+    const int kb = wave * per, ke = kb + per < K ? kb + per : K;
+    const bool row_ok = m0 + r < M, col_ok = n0 + r < N;
+    const float* Ar = tA ? A + m0 + r : A + (size_t)(m0 + r) * lda;  // element (m0 + r, k): Ar[k * lda] (tA) / Ar[k]
+    const float* Bc = tB ? B + (size_t)(n0 + r) * ldb : B + n0 + r;  // element (k, n0 + r): Bc[k] (tB) / Bc[k * ldb]
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kb; k0 < ke; k0 += 16 * SG_STEPS) {
+        float av[SG_STEPS][4], bv[SG_STEPS][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            // A chunk [16][64]: thread (ty, tx) takes k = tx + 16 q of row ty when A is row-major (k contiguous), or rows tx of
-            // k = ty + 16 q when it is stored transposed (m contiguous); B likewise -- the contiguous index goes to tx
-            const int ar = tA ? tx : ty, ak = k0 + (tA ? ty : tx) + 16 * q;
-            av[q] = (m0 + ar < M && ak < K) ? (tA ? A[(size_t)ak * lda + m0 + ar] : A[(size_t)(m0 + ar) * lda + ak]) : 0.f;
-            const int bc = tB ? ty : tx, bk = k0 + (tB ? tx : ty) + 16 * q;
-            bv[q] = (n0 + bc < N && bk < K) ? (tB ? B[(size_t)(n0 + bc) * ldb + bk] : B[(size_t)bk * ldb + n0 + bc]) : 0.f;
-        }
+        for (int st = 0; st < SG_STEPS; ++st)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            As[tA ? tx : ty][(tA ? ty : tx) + 16 * q] = av[q];
-            Bs[(tB ? tx : ty) + 16 * q][tB ? ty : tx] = bv[q];
-        }
-        __syncthreads();
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 16 * st + 4 * g + u;
+                av[st][u] = (row_ok && k < ke) ? (tA ? Ar[(size_t)k * lda] : Ar[k]) : 0.f;
+                bv[st][u] = (col_ok && k < ke) ? (tB ? Bc[k] : Bc[(size_t)k * ldb]) : 0.f;
+            }
 #pragma unroll
-        for (int k = 0; k < KC; ++k) acc += As[ty][k] * Bs[k][tx];
-        __syncthreads();
+        for (int st = 0; st < SG_STEPS; ++st)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][u], bv[st][u], acc, 0, 0, 0);
     }
-    if (m < M && n < N) {
-        float v = alpha * acc;
-        if (bias) v += bias[n];
-        if (beta != 0.f) v += beta * C[(size_t)m * ldc + n];
-        C[(size_t)m * ldc + n] = v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[wave][4 * g + q][r] = acc[q];  // D: column lane & 15, rows 4 (lane >> 4) + q
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15, m = m0 + ty, n = n0 + tx;
+        if (m < M && n < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < SG_WAVES; ++w) v += part[w][ty][tx];
+            v *= alpha;
+            if (bias) v += bias[n];
+            if (beta != 0.f) v += beta * C[(size_t)m * ldc + n];
+            C[(size_t)m * ldc + n] = v;
+        }
     }
 }
 
 int launch_sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb, float beta,
                  float* C, int ldc, const float* bias, hipStream_t s) {
     ARG_CHECK(A && B && C && M > 0 && N > 0 && K > 0, "sgemm: bad arguments M=%d N=%d K=%d", M, N, K);
-    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, s, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
+    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(SG_WAVES * 64), 0, s, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
 }
