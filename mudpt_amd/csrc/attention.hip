@@ -346,9 +346,11 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
     const elem* Of = (const elem*)fwd_out + (size_t)b * L * ldof + hd * 64;
 
     struct Frags { vec8 q0, q1, g0, g1, o0, o1; };
+    // window form (AttnArgs::win_n): a block without a wanted row only contributes delta -- its Q fragments are not fetched
+    auto in_win = [&](int blk) { return p.win_n <= 0 || (blk * 16 < p.win_row0 + p.win_n && blk * 16 + 16 > p.win_row0); };
     auto fetch = [&](int qb) {
-        const int q = qb * 16 + c;
-        return Frags{A::grow(base, ld, q, L, 0, lane), A::grow(base, ld, q, L, 1, lane), A::grow(dO, HD, q, L, 0, lane),
+        const int q = qb * 16 + c, lq = in_win(qb) ? L : 0;  // lq = 0: grow() returns zeros without touching memory (wave-uniform)
+        return Frags{A::grow(base, ld, q, lq, 0, lane), A::grow(base, ld, q, lq, 1, lane), A::grow(dO, HD, q, L, 0, lane),
                      A::grow(dO, HD, q, L, 1, lane), A::grow(Of, ldof, q, L, 0, lane), A::grow(Of, ldof, q, L, 1, lane)};
     };
     // the first block's Q / dO / O fragments travel during the K / V staging, the second block's during the first block's compute
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
         const size_t stat = ((size_t)b * p.H + hd) * Lp + q;
         if (g == 0) p.delta[stat] = delta;
         // window form: delta of EVERY query (the dK / dV pass sums over all of them), dQ only for the blocks that hold a wanted row
-        if (p.win_n > 0 && (qb * 16 >= p.win_row0 + p.win_n || qb * 16 + 16 <= p.win_row0)) return;
+        if (!in_win(qb)) return;
         const float nlse = -lse_q * LOG2E;
         const int nkc = CAUSAL ? (qb >> 1) + 1 : NC;
 
@@ -441,10 +443,11 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
     // this wave's (at most two) key blocks: K / V fragments requested before the Q / dO staging
     const int nkb = (L + 15) >> 4, kbA = wave, kbB = wave + NC;
     struct Frags { vec8 k0, k1, v0, v1; };
+    auto in_win = [&](int blk) { return p.win_n <= 0 || (blk * 16 < p.win_row0 + p.win_n && blk * 16 + 16 > p.win_row0); };
     auto fetch = [&](int kb) {
-        const int key = kb * 16 + c;
-        return Frags{A::grow(base + HD, ld, key, L, 0, lane), A::grow(base + HD, ld, key, L, 1, lane),
-                     A::grow(base + 2 * HD, ld, key, L, 0, lane), A::grow(base + 2 * HD, ld, key, L, 1, lane)};
+        const int key = kb * 16 + c, lk = in_win(kb) ? L : 0;  // window form: blocks without a wanted key row fetch nothing
+        return Frags{A::grow(base + HD, ld, key, lk, 0, lane), A::grow(base + HD, ld, key, lk, 1, lane),
+                     A::grow(base + 2 * HD, ld, key, lk, 0, lane), A::grow(base + 2 * HD, ld, key, lk, 1, lane)};
     };
     const Frags fa = fetch(kbA), fb = fetch(kbB);
     // the row statistics (Lp = NT / 2 values: one per thread) are requested with the fragments, BEFORE the staging waits for
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int qc_sel = p.sel_rows ? (p.sel_rows[b] - b * L) >> 5 : -1;  // dO is zero outside this 32-query chunk
     auto block = [&](int kb, const Frags& f) {
         const int key = kb * 16 + c;
-        if (p.win_n > 0 && (kb * 16 >= p.win_row0 + p.win_n || kb * 16 + 16 <= p.win_row0)) return;  // window form: no wanted key row in this block
+        if (!in_win(kb)) return;  // window form: no wanted key row in this block
         const vec8 k0 = f.k0, k1 = f.k1, v0 = f.v0, v1 = f.v1;
         f32x4 dK[4], dV[4];
 #pragma unroll
