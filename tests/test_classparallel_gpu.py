@@ -203,3 +203,29 @@ def test_two_processes_gloo_208_classes_match_reference(tmp_path, dtype):
     for rk in z["ranks"]:  # eval mode: same logits as the training forward (dropout-free model), cache reuse changes nothing
         assert torch.equal(rk["eval"], rk["eval_reuse"])
         assert (rk["eval"] - rk["logits"]).abs().max().item() <= 1e-6
+
+
+def test_plugin_runs_class_parallel_at_world_2(tmp_path):
+    """The trainer PLUGIN under torch.distributed.run with two ranks (gloo, both on the box's one GPU), once with the class-parallel text
+    tower (MUDPT_CLASS_PARALLEL=1) and once replicated: `build_model` shards the classes, `forward_backward` and the test pass go through
+    the phases, the replicas hold bit-identical parameters after two steps, and the two modes agree on losses, accuracy and parameters up to
+    the rounding noise of two differently ordered backward passes."""
+    res = {}
+    for mode in ("1", "0"):
+        out = str(tmp_path / f"plugin{mode}")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MUDPT_CLASS_PARALLEL=mode)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+               os.path.join(ROOT, "tests", "plugin_cp_worker.py"), out]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        r0, r1 = torch.load(out + ".r0", weights_only=True), torch.load(out + ".r1", weights_only=True)
+        assert torch.equal(r0["params"], r1["params"]), "replicas diverged"
+        assert r0["acc"] == r1["acc"]
+        res[mode] = (r0, r1)
+    assert res["1"][0]["shard"] == (0, 6) and res["1"][1]["shard"] == (6, 11) and res["0"][0]["shard"] is None
+    a, b = res["1"][0], res["0"][0]
+    assert abs(a["losses"][0] - b["losses"][0]) <= 1e-5 * max(1.0, abs(b["losses"][0]))  # same forward: the first loss is the same number
+    assert abs(a["losses"][1] - b["losses"][1]) <= 5e-3
+    assert a["acc"] == b["acc"]
+    moved = (b["params"] - a["params"]).abs().max().item()
+    assert moved <= 2e-3, moved
