@@ -4,6 +4,7 @@ Run in the build container only (needs /root/reference, which never travels to t
 
     python tests/golden/gen_golden.py            # writes tests/golden/*.npz
     python tests/golden/gen_golden.py --cocoop-only   # only the CoCoOp fixtures (trainers/cocoop.py)
+    python tests/golden/gen_golden.py --cocoop-many-only   # only the 48-class CoCoOp fixture (mixed prompt lengths)
     python tests/golden/gen_golden.py --many-only     # only the 208-class fixture (BASELINE configs[2]'s text-heavy shape)
 
 What runs: ``clip.model.CLIP`` and ``trainers.mudpt.CustomCLIP`` imported unmodified from
@@ -202,8 +203,10 @@ def run(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, t
           f"{os.path.getsize(path) / 1e6:.2f} MB")
 
 
-def run_cocoop(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, train_seed: int, image_seed: int):
-    """CoCoOp fixtures from the reference's own trainers/cocoop.py CustomCLIP over the vanilla CLIP (cfg=None, cocoop.py:38)."""
+def run_cocoop(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, train_seed: int, image_seed: int, classnames=None):
+    """CoCoOp fixtures from the reference's own trainers/cocoop.py CustomCLIP over the vanilla CLIP (cfg=None, cocoop.py:38).
+    classnames: None = the 11 benchmark names; a list = the many-class case (mixed prompt lengths: a different EOT row per class)."""
+    CLASSNAMES = globals()["CLASSNAMES"] if classnames is None else list(classnames)
     from oracle import cocoop_oracle as CO
     clip, cm, _mudpt, CN = import_reference()
     from trainers import cocoop
@@ -227,7 +230,7 @@ def run_cocoop(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed:
         p.requires_grad_("prompt_learner" in k)
     assert sorted(k for k, p in model.named_parameters() if p.requires_grad) == sorted(CO.TRAINABLE_ORDER)
     images = seeded_images(cfg, batch, image_seed)
-    labels = torch.arange(batch) * 3 % len(CLASSNAMES)
+    labels = torch.arange(batch) * 3 % len(CLASSNAMES) if classnames is None else (torch.arange(batch) * 29 + 5) % len(CLASSNAMES)
     model.eval()
     with torch.no_grad():
         logits = model(images)          # eval mode returns logits (cocoop.py:198)
@@ -288,9 +291,13 @@ if __name__ == "__main__":
     if "--vitl-only" in sys.argv:
         run(O.VIT_L14_336, "mudpt_vitl14_336_b1", "a photo of a", batch=1, frozen_seed=5, train_seed=6, image_seed=77, sample_big=True)
         sys.exit(0)
+    if "--cocoop-many-only" in sys.argv:
+        run_cocoop(O.VIT_B16, "cocoop_vitb16_c48_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=6, image_seed=777, classnames=many_classnames(48))
+        sys.exit(0)
     if "--cocoop-only" in sys.argv:
         run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
         run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)
+        run_cocoop(O.VIT_B16, "cocoop_vitb16_c48_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=6, image_seed=777, classnames=many_classnames(48))
         sys.exit(0)
     run(O.TINY, "mudpt_tiny", "a photo", batch=3, frozen_seed=11, train_seed=12, image_seed=13, sample_big=False)
     run(O.VIT_B16, "mudpt_vitb16_b4", "a photo of a", batch=4, frozen_seed=0, train_seed=1, image_seed=1234,
@@ -300,4 +307,5 @@ if __name__ == "__main__":
         sample_big=True, classnames=many_classnames(208), taps_wanted=False)
     run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
     run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)
+    run_cocoop(O.VIT_B16, "cocoop_vitb16_c48_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=6, image_seed=777, classnames=many_classnames(48))
     run_tokenizer()
