@@ -4,6 +4,7 @@ Run in the build container only (needs /root/reference, which never travels to t
 
     python tests/golden/gen_golden.py            # writes tests/golden/*.npz
     python tests/golden/gen_golden.py --cocoop-only   # only the CoCoOp fixtures (trainers/cocoop.py)
+    python tests/golden/gen_golden.py --defaults-only      # only the n_ctx 2 / depth 9 fixture (what the reference's scripts train)
     python tests/golden/gen_golden.py --cocoop-many-only   # only the 48-class CoCoOp fixture (mixed prompt lengths)
     python tests/golden/gen_golden.py --many-only     # only the 208-class fixture (BASELINE configs[2]'s text-heavy shape)
 
@@ -291,6 +292,12 @@ if __name__ == "__main__":
     if "--vitl-only" in sys.argv:
         run(O.VIT_L14_336, "mudpt_vitl14_336_b1", "a photo of a", batch=1, frozen_seed=5, train_seed=6, image_seed=77, sample_big=True)
         sys.exit(0)
+    if "--defaults-only" in sys.argv:
+        # the configuration the reference's scripts actually train: they never pass TRAINER.MUDPT.*, so the code defaults apply -- N_CTX 2
+        # (train.py:116-118) -- with the shipped yaml's depth 9 (configs/trainers/MuDPT/vit_b16_bz4_ep10_nctx4_depth9.yaml)
+        import dataclasses
+        run(dataclasses.replace(O.VIT_B16, n_ctx=2, depth=9), "mudpt_vitb16_n2_d9_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=8, image_seed=99, sample_big=True)
+        sys.exit(0)
     if "--cocoop-many-only" in sys.argv:
         run_cocoop(O.VIT_B16, "cocoop_vitb16_c48_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=6, image_seed=777, classnames=many_classnames(48))
         sys.exit(0)
@@ -305,6 +312,8 @@ if __name__ == "__main__":
     run(O.VIT_L14_336, "mudpt_vitl14_336_b1", "a photo of a", batch=1, frozen_seed=5, train_seed=6, image_seed=77, sample_big=True)
     run(O.VIT_B16, "mudpt_vitb16_c208_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=3, image_seed=2468,
         sample_big=True, classnames=many_classnames(208), taps_wanted=False)
+    import dataclasses
+    run(dataclasses.replace(O.VIT_B16, n_ctx=2, depth=9), "mudpt_vitb16_n2_d9_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=8, image_seed=99, sample_big=True)
     run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
     run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)
     run_cocoop(O.VIT_B16, "cocoop_vitb16_c48_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=6, image_seed=777, classnames=many_classnames(48))

@@ -31,7 +31,7 @@ def build(case: GoldenCase, dtype: str, max_batch=None, knobs=None):
     return m
 
 
-@pytest.fixture(scope="module", params=["mudpt_tiny", "mudpt_vitb16_b4", "mudpt_vitl14_336_b1"])
+@pytest.fixture(scope="module", params=["mudpt_tiny", "mudpt_vitb16_b4", "mudpt_vitl14_336_b1", "mudpt_vitb16_n2_d9_b2"])  # the last: n_ctx 2, depth 9 -- what the reference's scripts train
 def case(request):
     return GoldenCase(request.param)
 

@@ -7,7 +7,7 @@ from oracle import mudpt_oracle as O
 from tests.helpers import GoldenCase
 
 
-@pytest.fixture(scope="module", params=["mudpt_tiny", "mudpt_vitb16_b4", "mudpt_vitl14_336_b1"])
+@pytest.fixture(scope="module", params=["mudpt_tiny", "mudpt_vitb16_b4", "mudpt_vitl14_336_b1", "mudpt_vitb16_n2_d9_b2"])  # the last: n_ctx 2, depth 9 -- what the reference's scripts train
 def case(request):
     c = GoldenCase(request.param)
     c.check_recipe()
