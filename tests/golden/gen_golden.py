@@ -5,6 +5,7 @@ Run in the build container only (needs /root/reference, which never travels to t
     python tests/golden/gen_golden.py            # writes tests/golden/*.npz
     python tests/golden/gen_golden.py --cocoop-only   # only the CoCoOp fixtures (trainers/cocoop.py)
     python tests/golden/gen_golden.py --defaults-only      # only the n_ctx 2 / depth 9 fixture (what the reference's scripts train)
+    python tests/golden/gen_golden.py --cocoop-b32-only    # only the ViT-B/32 batch-1 CoCoOp fixture (the reference's CoCoOp yaml)
     python tests/golden/gen_golden.py --cocoop-many-only   # only the 48-class CoCoOp fixture (mixed prompt lengths)
     python tests/golden/gen_golden.py --many-only     # only the 208-class fixture (BASELINE configs[2]'s text-heavy shape)
 
@@ -298,6 +299,11 @@ if __name__ == "__main__":
         import dataclasses
         run(dataclasses.replace(O.VIT_B16, n_ctx=2, depth=9), "mudpt_vitb16_n2_d9_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=8, image_seed=99, sample_big=True)
         sys.exit(0)
+    if "--cocoop-b32-only" in sys.argv:
+        # the reference's own CoCoOp configuration: ViT-B/32, batch 1 (configs/trainers/CoCoOp/vit_b32_bz1_ep10_ctxv1.yaml)
+        import dataclasses
+        run_cocoop(dataclasses.replace(O.VIT_B16, patch=32), "cocoop_vitb32_b1", "a photo of a", batch=1, frozen_seed=3, train_seed=4, image_seed=55)
+        sys.exit(0)
     if "--cocoop-many-only" in sys.argv:
         run_cocoop(O.VIT_B16, "cocoop_vitb16_c48_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=6, image_seed=777, classnames=many_classnames(48))
         sys.exit(0)
@@ -317,4 +323,5 @@ if __name__ == "__main__":
     run_cocoop(O.TINY, "cocoop_tiny", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23)
     run_cocoop(O.VIT_B16, "cocoop_vitb16_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321)
     run_cocoop(O.VIT_B16, "cocoop_vitb16_c48_b2", "a photo of a", batch=2, frozen_seed=0, train_seed=6, image_seed=777, classnames=many_classnames(48))
+    run_cocoop(dataclasses.replace(O.VIT_B16, patch=32), "cocoop_vitb32_b1", "a photo of a", batch=1, frozen_seed=3, train_seed=4, image_seed=55)
     run_tokenizer()

@@ -49,7 +49,7 @@ def build(cfg, frozen, tokens, params, dtype, max_batch, knobs=None):
 
 # cocoop_vitb16_c48_b2: 48 class names of 1-9 words from the reference (EOT rows 7..25): the trimmed text tower runs 26 positions with a different
 # EOT row per class, 96 sequences per step
-@pytest.fixture(scope="module", params=["cocoop_tiny", "cocoop_vitb16_b2", "cocoop_vitb16_c48_b2"])
+@pytest.fixture(scope="module", params=["cocoop_tiny", "cocoop_vitb16_b2", "cocoop_vitb16_c48_b2", "cocoop_vitb32_b1"])  # the last: the reference's CoCoOp yaml (ViT-B/32, batch 1)
 def case(request):
     return GoldenCase(request.param)
 

@@ -77,7 +77,7 @@ def test_flat_bucket_roundtrip():
     assert O.flatten(O.make_trainable_state(O.VIT_B16, 1)).numel() == 1243136
 
 
-@pytest.mark.parametrize("name", ["cocoop_tiny", "cocoop_vitb16_b2", "cocoop_vitb16_c48_b2"])
+@pytest.mark.parametrize("name", ["cocoop_tiny", "cocoop_vitb16_b2", "cocoop_vitb16_c48_b2", "cocoop_vitb32_b1"])
 def test_cocoop_forward_backward_matches_reference(name):
     """The CoCoOp restatement (oracle/cocoop_oracle.py) against the reference's trainers/cocoop.py CustomCLIP: eval-mode
     logits, training-mode loss (cross-entropy inside forward) and the gradients of ctx and meta_net."""
