@@ -133,21 +133,20 @@ def test_unused_deep_prompts_get_zero_grad():
     m.close()
 
 
-def test_sgd_step_matches_torch():
+@pytest.mark.parametrize("nesterov,dampening", [(False, 0.0), (True, 0.0), (False, 0.1)])
+def test_sgd_step_matches_torch(nesterov, dampening):
+    """The library's fused SGD over two steps against the oracle's torch.optim.SGD restatement (itself held to torch.optim.SGD on CPU,
+    tests/test_oracle_golden.py), incl. the nesterov and dampening variants Dassl's build_optimizer can configure."""
     case = GoldenCase("mudpt_tiny")
     m = build(case, "fp16")
-    p0 = m.flat_params.clone()
-    m.forward_backward(case.images, case.labels)
-    g0 = m.flat_grads.clone()
-    m.sgd_step(lr=0.0025, momentum=0.9, weight_decay=5e-4)
-    ref, buf = O.sgd_step(p0.cpu(), g0.cpu(), None, 0.0025)
-    torch.testing.assert_close(m.flat_params.cpu(), ref, atol=1e-7, rtol=1e-6)
-    m.forward_backward(case.images, case.labels)
-    g1 = m.flat_grads.clone()
-    p1 = m.flat_params.clone()
-    m.sgd_step(lr=0.0025, momentum=0.9, weight_decay=5e-4)
-    ref2, _ = O.sgd_step(p1.cpu(), g1.cpu(), buf, 0.0025)
-    torch.testing.assert_close(m.flat_params.cpu(), ref2, atol=1e-7, rtol=1e-6)
+    buf = None
+    for _ in range(2):
+        p0 = m.flat_params.clone()
+        m.forward_backward(case.images, case.labels)
+        g0 = m.flat_grads.clone()
+        m.sgd_step(lr=0.0025, momentum=0.9, weight_decay=5e-4, dampening=dampening, nesterov=nesterov)
+        ref, buf = O.sgd_step(p0.cpu(), g0.cpu(), buf, 0.0025, 0.9, 5e-4, dampening, nesterov)
+        torch.testing.assert_close(m.flat_params.cpu(), ref, atol=1e-7, rtol=1e-6)
     m.close()
 
 

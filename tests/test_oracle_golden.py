@@ -92,3 +92,20 @@ def test_cocoop_forward_backward_matches_reference(name):
         scale = ref.pow(2).mean().sqrt().item()
         torch.testing.assert_close(grads[k], ref, atol=1e-3 * scale + 1e-9, rtol=1e-4)
     assert CO.flatten(case.params).numel() == sum(int(np.prod(s)) for s in CO.trainable_shapes(case.cfg).values())
+
+
+@pytest.mark.parametrize("nesterov,dampening", [(False, 0.0), (True, 0.0), (False, 0.1)])
+def test_sgd_restatement_equals_torch_optim(nesterov, dampening):
+    """oracle.sgd_step -- the checker of the library's fused SGD -- against torch.optim.SGD itself (what Dassl's build_optimizer("sgd") runs
+    behind trainers/mudpt.py:225,251) over four steps with momentum, weight decay, and the nesterov / dampening variants."""
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(257, generator=g)
+    grads = [torch.randn(257, generator=g) for _ in range(4)]
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9, weight_decay=5e-4, dampening=dampening, nesterov=nesterov)
+    q, buf = p0.clone(), None
+    for gr in grads:
+        p.grad = gr.clone()
+        opt.step()
+        q, buf = O.sgd_step(q, gr, buf, 0.01, 0.9, 5e-4, dampening, nesterov)
+        torch.testing.assert_close(q, p.detach(), atol=1e-7, rtol=1e-6)
