@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--no-last-single", action="store_true", help="last block through the general attention kernels on all rows (A/B of the single-query path)")
     ap.add_argument("--class-parallel", action="store_true", help="N > 1: each rank encodes C / N class prompts (two extra [C, embed] sums per step); "
                     "meant for --classes 1000 (BASELINE configs[2])")
+    ap.add_argument("--no-split-k", action="store_true", help="never split the contraction of the small-grid GEMMs (A/B at small batches)")
     ap.add_argument("--no-attn-window", action="store_true", help="block 0's attention backward on all rows (A/B of the prompt-row window form)")
     ap.add_argument("--txt-buckets", type=int, default=0, help="maximum number of length buckets of the class prompts (0 = library default 3; 1 = none)")
     ap.add_argument("--fp32-streams", action="store_true", help="keep the gradient stream (and in bf16 mode the update stream) in fp32 (A/B of the T streams)")
@@ -122,6 +123,8 @@ def main():
         knobs["attn_two_kernels"] = 1
     if args.txt_buckets:
         knobs["txt_buckets"] = args.txt_buckets
+    if args.no_split_k:
+        knobs["split_k"] = 0
     if args.no_attn_window:
         knobs["attn_window"] = 0
     if args.no_last_single:

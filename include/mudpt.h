@@ -155,6 +155,7 @@ int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* hos
 
 /* Per-handle tuning knobs for A/B measurements in one process (tools/gemm_bench.py, tests); nothing is process-global, so two
  * models in one process do not interfere: "gemm_variant"; "attn_window" (0 = block 0's attention backward on all rows instead of the prompt rows' blocks);
+ * "split_k" (0 = never split the contraction of the small-grid, long-K GEMMs);
  * "last_single" (0 = the last block's attention on all rows instead of the
  * single-query form); "attn_two_kernels" (1 = attention backward as two kernels); "cocoop_chunk"
  * (cap on the images per CoCoOp text-tower pass; read by the next mudpt_set_class_prompts); "lp_grad" (gradient stream of the residual in T: default in bf16 mode, where 0 also returns the forward's update stream to fp32;

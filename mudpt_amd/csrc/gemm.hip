@@ -43,8 +43,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     const int m0 = (wg / ntn) * BM;
     const int n0 = (wg % ntn) * BN;
 
-    const elem* __restrict__ A = (const elem*)p.A;
-    const elem* __restrict__ Bw = (const elem*)p.B;
+    // split K: slice blockIdx.y of the contraction (gridDim.y = 1 and ksplit = 0 otherwise)
+    const int kz = blockIdx.y, kspan = p.ksplit ? p.ksplit : p.K;
+    const elem* __restrict__ A = (const elem*)p.A + (size_t)kz * kspan;
+    const elem* __restrict__ Bw = (const elem*)p.B + (size_t)kz * kspan;
 
     // per-lane source pointers (k offset advances by BK per tile); rows clamped at the ragged edge
     const int srow = lane >> 3;                       // row inside the 8-row group this lane fills
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     // plain double buffer (2 workgroups per CU hide each other's waits); NS = 4 is for grids smaller than the chip (the text
     // tower's 99-row GEMMs: a handful of workgroups, each a pure latency chain over K).
     static_assert(NS >= 2 && (NS & (NS - 1)) == 0, "ring depth must be a power of two");
-    const int nt = p.K / BK;
+    const int nt = kspan / BK;
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st)
         if (st < nt) stage(st, st);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
                 const f32x4 q4 = *(const f32x4*)(posrow + n);
                 *(f32x4*)((float*)p.out0 + orow * p.ldo0 + n) = v + q4;
             } else {  // EPI_STORE_F32
-                *(f32x4*)((float*)p.out0 + orow * p.ldo0 + n) = v;
+                *(f32x4*)((float*)p.out0 + (size_t)kz * p.split_stride + orow * p.ldo0 + n) = v;
             }
         }
     }
@@ -186,7 +188,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
         pd.done[dev] = true;
     }
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn, a.ksplit ? a.K / a.ksplit : 1), dim3(WM * WN * 64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
 }
@@ -225,6 +227,45 @@ static int launch_t(int epi, const GemmArgs& a, hipStream_t s, int variant) {
     return MUDPT_ERR_ARG;
 }
 
+// out[m][n] = sum over the S split-K slices (in slice order: bitwise reproducible) of part[z][m][n] (+ bias[n]), as T or fp32
+template <typename T, bool OUT_F32>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, size_t stride, int M, int N, const float* __restrict__ bias,
+                                                            void* __restrict__ out, int ldo) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n4 = (size_t)N / 4;
+    if (i >= (size_t)M * n4) return;
+    const size_t m = i / n4, n = (i - m * n4) * 4;
+    f32x4 v = *(const f32x4*)(part + m * N + n);
+    for (int z = 1; z < S; ++z) v += *(const f32x4*)(part + (size_t)z * stride + m * N + n);
+    if (bias) v += *(const f32x4*)(bias + n);
+    if constexpr (OUT_F32) {
+        *(f32x4*)((float*)out + m * ldo + n) = v;
+    } else {
+        using elem = typename T::elem;
+        typename T::vec4 o = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
+        *(typename T::vec4*)((elem*)out + m * ldo + n) = o;
+    }
+}
+
+// Split K for the store GEMMs whose grid is a fraction of the chip and whose contraction is long (small batches: M = B L = 804 rows at
+// the reference's training batch of 4, K = 2304 / 3072): a 128 x 64 tile per workgroup leaves 2/3 of the CUs idle while every workgroup
+// walks 36-48 K-steps.  S slices of K fill the chip; their fp32 partials go through the caller's scratch and are summed in slice order.
+static int split_k_slices(int epi, const GemmArgs& a, const GemmOpts& o) {
+    if (!(epi == EPI_STORE || epi == EPI_STORE_F32) || !o.scratch || (o.variant & 0xff) != 0) return 1;
+    static PerDevice pd;
+    const int dev = current_device();
+    if (!pd.done[dev]) {
+        if (hipDeviceGetAttribute(&pd.ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
+        pd.done[dev] = true;
+    }
+    const size_t tiles = (size_t)((a.M + 127) / 128) * ((a.N + 63) / 64);
+    if (tiles * 2 > (size_t)pd.ncu[dev] || a.K < 1536) return 1;
+    int S = (int)((size_t)pd.ncu[dev] / tiles);
+    if (S > 4) S = 4;
+    while (S > 1 && (a.K % (S * 64) != 0 || a.K / S < 512)) --S;
+    if ((size_t)S * a.M * a.N > o.scratch_elems) return 1;
+    return S;
+}
+
 // default dispatch: the persistent ping-pong kernel takes the big GEMMs whose epilogue needs no operand load besides bias / u
 bool gemm_uses_pp(int epi, const GemmArgs& a, int variant) {
     const bool pp_epi = epi == EPI_STORE || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32;
@@ -251,6 +292,19 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const Gemm
     b.flags |= ((variant >> 12) & 0xff) << 8;  // bits 12..19 of the knob: column-tile group width GN of gemm_pp (0 = default)
     // default: the persistent ping-pong kernel for the big GEMMs whose epilogue needs no operand load besides bias / u
     if (gemm_uses_pp(epi, a, o.variant)) return launch_gemm_pp(dtype, epi, b, s, o);
+    if (const int S = split_k_slices(epi, a, o); S > 1) {
+        GemmArgs q = b;
+        q.bias = nullptr; q.out0 = o.scratch; q.ldo0 = a.N; q.ksplit = a.K / S; q.split_stride = (size_t)a.M * a.N;
+        if (dtype == DT_BF16) { if (int rc = launch_cfg<BF16, 128, 64, 2, 2, EPI_STORE_F32, 4>(q, s)) return rc; }
+        else if (dtype == DT_F16) { if (int rc = launch_cfg<F16, 128, 64, 2, 2, EPI_STORE_F32, 4>(q, s)) return rc; }
+        else { set_error("gemm: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
+        const unsigned grid = (unsigned)(((size_t)a.M * (a.N / 4) + 255) / 256);
+        if (epi == EPI_STORE_F32) hipLaunchKernelGGL((splitk_reduce_kernel<BF16, true>), dim3(grid), dim3(256), 0, s, o.scratch, S, q.split_stride, a.M, a.N, a.bias, a.out0, a.ldo0);
+        else if (dtype == DT_BF16) hipLaunchKernelGGL((splitk_reduce_kernel<BF16, false>), dim3(grid), dim3(256), 0, s, o.scratch, S, q.split_stride, a.M, a.N, a.bias, a.out0, a.ldo0);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<F16, false>), dim3(grid), dim3(256), 0, s, o.scratch, S, q.split_stride, a.M, a.N, a.bias, a.out0, a.ldo0);
+        HIP_TRY(hipGetLastError());
+        return MUDPT_OK;
+    }
     if (dtype == DT_BF16) return launch_t<BF16>(epi, b, s, o.variant);
     if (dtype == DT_F16) return launch_t<F16>(epi, b, s, o.variant);
     set_error("gemm: unknown dtype %d", dtype);

@@ -31,11 +31,16 @@ struct GemmArgs {
     int flags = 0;                 // bit 0: no XCD remap of the block id (tuning)
     int patches = 0, seq_len = 0;  // EPI_PATCH: P, L
     const float* pos = nullptr;    // EPI_PATCH: [1 + P, N]
+    // split K (gemm_nt_kernel, EPI_STORE_F32 partials): slice z = blockIdx.y contracts k in [z * ksplit, (z + 1) * ksplit) and writes its
+    // fp32 partial tile set to out0 + z * split_stride elements; launch_gemm sums the slices in order afterwards (splitk_reduce_kernel)
+    int ksplit = 0; size_t split_stride = 0;
 };
 // Host-side options of one launch (never passed to the device): they belong to the calling model handle, not to the process.
 struct GemmOpts {
     int variant = 0;                                 // tuning knob, see gemm.hip (mudpt_model_set "gemm_variant")
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // if set, a gemm_pp_kernel launch records them (start / end of the kernel)
+    // fp32 scratch of the calling stream (one per tower: the towers run concurrently) for split-K partials; null = never split
+    float* scratch = nullptr; size_t scratch_elems = 0;
 };
 int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o = GemmOpts());
 bool gemm_uses_pp(int epi, const GemmArgs& a, int variant = 0);  // true if launch_gemm dispatches to gemm_pp_kernel

@@ -113,6 +113,37 @@ def test_gemm_epilogues(lib, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(804, 768, 3072), (804, 768, 2304), (450, 512, 2048), (201, 768, 3072), (1000, 768, 1536)])
+def test_gemm_split_k(lib, dtype, shape):
+    """Small grids with a long contraction (the reference's training batch of 4: M = 804) split K over up to 4 slices whose fp32 partials are
+    summed in slice order.  Small-integer operands make every sum exact, so the split result is BIT-exact (both store epilogues, bias
+    included); random operands agree with the unsplit kernel to fp32 rounding; run to run bit for bit."""
+    dt, tt = DT[dtype]
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randint(-2, 3, (M, K), generator=g).float()
+    B = (torch.arange(N).view(N, 1) % 5 - 2 + (torch.arange(K).view(1, K) % 3)).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    ref = A @ B.t() + bias
+    Ad, Bd, bd = A.cuda().to(tt), B.cuda().to(tt), bias.cuda()
+    o32 = torch.empty(M, N, device="cuda")
+    gemm(lib, dt, 5, Ad, Bd, bias=bd, out0=o32, variant=0x10000)
+    assert torch.equal(o32.cpu(), ref)
+    oT = torch.empty(M, N, device="cuda", dtype=tt)
+    gemm(lib, dt, 0, Ad, Bd, bias=bd, out0=oT, variant=0x10000)
+    assert torch.equal(oT.cpu(), ref.to(tt))
+    Ar, Br = torch.randn(M, K, generator=g).to(tt).cuda(), (torch.randn(N, K, generator=g) * K ** -0.5).to(tt).cuda()
+    a32, b32, c32 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    gemm(lib, dt, 5, Ar, Br, out0=a32)
+    gemm(lib, dt, 5, Ar, Br, out0=b32, variant=0x10000)
+    gemm(lib, dt, 5, Ar, Br, out0=c32, variant=0x10000)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(b32, a32, atol=2e-5 * K ** 0.5, rtol=1e-5)
+    assert torch.equal(b32, c32)
+    assert not torch.equal(b32, a32) or K < 1536  # the split path really ran (a different summation order shows in the last bits)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_gemm_patch_epilogue(lib, dtype):
     """Patch-embed GEMM: row m of the im2col matrix lands on token row (m / P) * L + 1 + m % P, plus pos-emb."""
     dt, tt = DT[dtype]
