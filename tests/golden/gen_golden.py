@@ -8,6 +8,7 @@ Run in the build container only (needs /root/reference, which never travels to t
     python tests/golden/gen_golden.py --cocoop-b32-only    # only the ViT-B/32 batch-1 CoCoOp fixture (the reference's CoCoOp yaml)
     python tests/golden/gen_golden.py --cocoop-many-only   # only the 48-class CoCoOp fixture (mixed prompt lengths)
     python tests/golden/gen_golden.py --many-only     # only the 208-class fixture (BASELINE configs[2]'s text-heavy shape)
+    python tests/golden/gen_golden.py --scale100-only # the *_s100 fixtures: logit_scale = ln 100, what pretrained CLIP checkpoints hold
 
 What runs: ``clip.model.CLIP`` and ``trainers.mudpt.CustomCLIP`` imported unmodified from
 /root/reference; their parameters are overwritten with the seeded recipe of
@@ -121,8 +122,16 @@ def many_classnames(n: int = 208):
     return names
 
 
+def with_logit_scale(frozen: dict, logit_scale) -> dict:
+    """logit_scale = None keeps CLIP's init value ln(1/0.07) (clip/model.py:777); a number stands for what a pretrained checkpoint
+    loaded through clip/model.py:919 holds (every released CLIP has exp(logit_scale) = 100 within a fraction of a percent)."""
+    if logit_scale is not None:
+        frozen["logit_scale"] = torch.tensor(float(np.log(logit_scale)))
+    return frozen
+
+
 def run(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, train_seed: int,
-        image_seed: int, sample_big: bool, classnames=None, taps_wanted: bool = True):
+        image_seed: int, sample_big: bool, classnames=None, taps_wanted: bool = True, logit_scale=None):
     CLASSNAMES = classnames or globals()["CLASSNAMES"]
     clip, cm, mudpt, CN = import_reference()
     ycfg = CN(TRAINER=CN(NAME="MuDPT", MUDPT=CN(N_CTX=cfg.n_ctx, CTX_INIT=ctx_init,
@@ -130,10 +139,11 @@ def run(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, t
               INPUT=CN(SIZE=(cfg.image_size, cfg.image_size)))
     ref_clip = cm.CLIP(cfg.embed_dim, cfg.image_size, cfg.v_layers, cfg.v_width, cfg.patch, cfg.ctx_len,
                        cfg.vocab, cfg.t_width, cfg.t_heads, cfg.t_layers, ycfg).float()
-    frozen = O.make_frozen_state(cfg, frozen_seed)
+    frozen = with_logit_scale(O.make_frozen_state(cfg, frozen_seed), logit_scale)
     missing, unexpected = ref_clip.load_state_dict(frozen, strict=False)
     assert not unexpected, unexpected
     assert all("visual_ctx" in k for k in missing), missing  # only the vision-side trainables
+    assert torch.equal(ref_clip.logit_scale.detach(), frozen["logit_scale"])
     model = mudpt.CustomCLIP(ycfg, CLASSNAMES, ref_clip)
 
     # ctx comes from the reference's own init (token embedding of ctx_init words, mudpt.py:57-64)
@@ -184,6 +194,7 @@ def run(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, t
                                      frozen["token_embedding.weight"].double().abs().sum().item()]),
         "logits": logits.detach().numpy(),
         "loss": np.array(loss.item(), dtype=np.float64),
+        "logit_scale": np.array(frozen["logit_scale"].item(), dtype=np.float32),  # the parameter (a log), as the state dict holds it
     }
     for k in O.TRAINABLE_ORDER:
         g = grads[k]
@@ -205,7 +216,7 @@ def run(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, t
           f"{os.path.getsize(path) / 1e6:.2f} MB")
 
 
-def run_cocoop(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, train_seed: int, image_seed: int, classnames=None):
+def run_cocoop(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed: int, train_seed: int, image_seed: int, classnames=None, logit_scale=None):
     """CoCoOp fixtures from the reference's own trainers/cocoop.py CustomCLIP over the vanilla CLIP (cfg=None, cocoop.py:38).
     classnames: None = the 11 benchmark names; a list = the many-class case (mixed prompt lengths: a different EOT row per class)."""
     CLASSNAMES = globals()["CLASSNAMES"] if classnames is None else list(classnames)
@@ -216,9 +227,10 @@ def run_cocoop(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed:
               INPUT=CN(SIZE=(cfg.image_size, cfg.image_size)))
     ref_clip = cm.CLIP(cfg.embed_dim, cfg.image_size, cfg.v_layers, cfg.v_width, cfg.patch, cfg.ctx_len,
                        cfg.vocab, cfg.t_width, cfg.t_heads, cfg.t_layers, None).float()
-    frozen = O.make_frozen_state(cfg, frozen_seed)
+    frozen = with_logit_scale(O.make_frozen_state(cfg, frozen_seed), logit_scale)
     missing, unexpected = ref_clip.load_state_dict(frozen, strict=False)
     assert not unexpected and not missing, (missing, unexpected)
+    assert torch.equal(ref_clip.logit_scale.detach(), frozen["logit_scale"])
     model = cocoop.CustomCLIP(ycfg, CLASSNAMES, ref_clip)
     tok = model.tokenized_prompts
     ctx_ids = [int(v) for v in clip.tokenize(ctx_init)[0, 1:1 + cfg.n_ctx]]
@@ -246,6 +258,7 @@ def run_cocoop(cfg: O.Config, name: str, ctx_init: str, batch: int, frozen_seed:
         "labels": labels.numpy().astype(np.int64),
         "images_checksum": np.array([images.double().sum().item(), images.double().abs().sum().item()]),
         "logits": logits.numpy(), "loss": np.array(loss.item(), dtype=np.float64),
+        "logit_scale": np.array(frozen["logit_scale"].item(), dtype=np.float32),
     }
     for k in CO.TRAINABLE_ORDER:
         out["grad." + k] = ref_params[k].grad.detach().numpy()
@@ -284,6 +297,15 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if "--tokenizer-only" in sys.argv:
         run_tokenizer()
+        sys.exit(0)
+    if "--scale100-only" in sys.argv:
+        # the same recipes with the logit scale pretrained CLIP checkpoints carry (exp(logit_scale) = 100 instead of the init value
+        # 1/0.07 = 14.29): a 7x larger multiplier on the cosine, i.e. north_star's 1e-3 logit bound asks for 1e-5 on the cosine
+        run(O.TINY, "mudpt_tiny_s100", "a photo", batch=3, frozen_seed=11, train_seed=12, image_seed=13, sample_big=True, taps_wanted=False, logit_scale=100.0)
+        run(O.VIT_B16, "mudpt_vitb16_b4_s100", "a photo of a", batch=4, frozen_seed=0, train_seed=1, image_seed=1234, sample_big=True,
+            taps_wanted=False, logit_scale=100.0)
+        run_cocoop(O.TINY, "cocoop_tiny_s100", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23, logit_scale=100.0)
+        run_cocoop(O.VIT_B16, "cocoop_vitb16_b2_s100", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321, logit_scale=100.0)
         sys.exit(0)
     if "--many-only" in sys.argv:
         # BASELINE configs[2]'s shape of work at fixture size: ViT-B/16, 208 class prompts of mixed length (EOT 7..17), B = 2

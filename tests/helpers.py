@@ -20,6 +20,8 @@ class GoldenCase:
         self.cfg = O.Config(**ast.literal_eval(str(z["config"])))
         fs, ts, is_ = (int(v) for v in z["seeds"])
         self.frozen = O.make_frozen_state(self.cfg, fs)
+        if "logit_scale" in z.files:  # the *_s100 fixtures: exp(logit_scale) = 100, what pretrained CLIP checkpoints hold (clip/model.py:919)
+            self.frozen["logit_scale"] = torch.tensor(float(z["logit_scale"]))
         self.tokens = torch.from_numpy(z["tokenized_prompts"]).long()
         self.eot = self.tokens.argmax(dim=-1)  # trainers/mudpt.py:154
         self.class_embedding = self.frozen["token_embedding.weight"][self.tokens]
