@@ -79,7 +79,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--classes", type=int, default=11)
     ap.add_argument("--arch", default="vit_b16", choices=["vit_b16", "vit_l14_336"], help="vit_l14_336 = BASELINE configs[4] (not the headline line)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"], help="bf16 = the throughput mode (headline); fp16 = fast parity mode (logits within "
+                    "1e-3 at logit scale 14.29); fp32 = the exact mode (split operands + fp32 attention forward: 2e-5 at logit scale 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--prof-stride", type=int, default=4, help="bracket every n-th persistent-GEMM launch with HIP events (1 = all; an event pair "
@@ -219,25 +220,28 @@ def main():
     model.close()
     del model
 
-    # the parity configuration (fp16 operands, fp32 residual / update / gradient streams, split text-tower operands: logits within 1e-3 of
-    # the reference) timed on the same box right after the bf16 headline, so the driver's record carries both
-    parity_ms = None
+    # The parity configurations, timed on the same box right after the bf16 headline so that the driver's record carries them:
+    #   exact ("fp32", include/mudpt.h MUDPT_F32): every forward GEMM operand a [hi | lo] fp16 pair, attention forward in fp32 -- the mode that
+    #       meets north_star's 1e-3 logit bound at the logit scale pretrained CLIP carries (100): tests/test_exact_gpu.py, max 1.5e-5;
+    #   fp16: fp16 operands, fp32 streams, split text-tower operands -- within 1e-3 at the init logit scale 14.29 only (4e-3 at 100).
+    parity_ms = {}
     if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_parity_mode and not args.graph:
-        pm = CustomCLIP(shape, synth.random_clip_state(shape, seed=0), tok, ctx_token_ids=synth.CTX_INIT_TOKENS, max_batch=B, dtype="fp16",
-                        device=f"cuda:{local}", seed=1)
-        for _ in range(3):
-            pm.forward_backward(images, labels)
-            pm.sgd_step(lr, momentum=0.9, weight_decay=5e-4)
-        torch.cuda.synchronize()
-        n_par = max(5, args.steps // 2)
-        t1 = time.perf_counter()
-        for _ in range(n_par):
-            pm.forward_backward(images, labels)
-            pm.sgd_step(lr, momentum=0.9, weight_decay=5e-4)
-        torch.cuda.synchronize()
-        parity_ms = (time.perf_counter() - t1) / n_par * 1e3
-        pm.close()
-        del pm
+        for mode in ("fp32", "fp16"):
+            pm = CustomCLIP(shape, synth.random_clip_state(shape, seed=0), tok, ctx_token_ids=synth.CTX_INIT_TOKENS, max_batch=B, dtype=mode,
+                            device=f"cuda:{local}", seed=1)
+            for _ in range(3):
+                pm.forward_backward(images, labels)
+                pm.sgd_step(lr, momentum=0.9, weight_decay=5e-4)
+            torch.cuda.synchronize()
+            n_par = max(5, args.steps // 2)
+            t1 = time.perf_counter()
+            for _ in range(n_par):
+                pm.forward_backward(images, labels)
+                pm.sgd_step(lr, momentum=0.9, weight_decay=5e-4)
+            torch.cuda.synchronize()
+            parity_ms[mode] = (time.perf_counter() - t1) / n_par * 1e3
+            pm.close()
+            del pm
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -289,9 +293,13 @@ def main():
                                # HIP-event time of the vision tower's launches, against the 8 TB/s spec; measured in hbm_kernels_steps extra
                                # steps right after the timed region (event pairs on every launch would slow the timed steps by 3 %)
                                "hbm_kernels": hbm, "hbm_kernels_steps": hbm_steps}
-        if parity_ms is not None:
-            out["parity_mode_ms_per_step"] = round(parity_ms, 3)
-            out["parity_mode"] = "dtype fp16: fp16 MFMA operands, fp32 residual / update / gradient streams, split text-tower operands (logits within 1e-3 of the reference: tests/test_model_gpu.py)"
+        if parity_ms:
+            out["parity_mode_ms_per_step"] = round(parity_ms["fp32"], 3)
+            out["parity_mode"] = ("dtype fp32 (exact mode): [hi | lo] fp16 operand pairs in every forward GEMM of both towers and the patch embedding, fp32 attention forward "
+                                  "(v_mfma_f32_16x16x4_f32), fp32 residual / update / gradient streams; logits within 1e-3 of the reference at logit scale 100 "
+                                  "(measured max 1.5e-5: tests/test_exact_gpu.py)")
+            out["fast_parity_mode_ms_per_step"] = round(parity_ms["fp16"], 3)
+            out["fast_parity_mode"] = "dtype fp16: fp16 operands, fp32 streams, split text-tower operands; logits within 1e-3 at the init logit scale 14.29 only (4e-3 at 100)"
         if collective is not None:
             out["collective"] = collective
         if world == 1 and not args.no_cpu_baseline:

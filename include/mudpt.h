@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MUDPT_ABI_VERSION 4
+#define MUDPT_ABI_VERSION 5
 
 #define MUDPT_OK 0
 #define MUDPT_ERR_ARG 1   /* bad argument / shape (the reference raises AssertionError, mudpt.py:52,55,190) */
@@ -45,6 +45,12 @@ extern "C" {
 
 #define MUDPT_BF16 0
 #define MUDPT_F16 1
+/* "Exact" mode, what PREC = "fp32" selects (the reference's CPU path is fp32 whatever PREC says: clip/clip.py:142-143): fp16 MFMA
+ * operands, but every forward GEMM operand is a [hi | lo] fp16 pair contracted against the (fp16-exact, as CLIP checkpoints store
+ * them) weights -- 22 significant bits --, pixels included, and the attention forward runs in fp32 on the matrix cores
+ * (v_mfma_f32_16x16x4_f32).  Meets north_star's 1e-3 logit bound at the logit scale pretrained checkpoints carry (100).  The backward
+ * is the MUDPT_F16 one. */
+#define MUDPT_F32 2
 
 #define MUDPT_VARIANT_MUDPT 0  /* trainers/mudpt.py: deep multi-modal prompts, 10 trainables */
 #define MUDPT_VARIANT_COCOOP 1 /* trainers/cocoop.py: instance-conditioned text prompts, 5 trainables; depth is ignored */
@@ -57,7 +63,7 @@ typedef struct mudpt_config {
     int32_t n_ctx, depth; /* TRAINER.MUDPT.N_CTX / DEEP_PROMPT_DEPTH (train.py:115-119) */
     int32_t n_cls;        /* number of class prompts */
     int32_t max_batch;    /* activations are sized for this many images */
-    int32_t dtype;        /* MUDPT_BF16 / MUDPT_F16: MFMA operand type (fp32 accumulate, fp32 residual stream) */
+    int32_t dtype;        /* MUDPT_BF16 / MUDPT_F16: MFMA operand type (fp32 accumulate, fp32 residual stream); MUDPT_F32: exact mode */
     int32_t variant;      /* MUDPT_VARIANT_*; CoCoOp runs max_batch * n_cls text sequences per step */
 } mudpt_config;
 
@@ -200,6 +206,10 @@ int mudpt_layernorm_bwd(int32_t dtype, const void* dy, int32_t lddy, int32_t dy_
 int mudpt_attention_padded_len(int32_t L);
 int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H,
                         int32_t causal, void* stream);
+/* The exact mode's forward (MUDPT_F32): q | k | v in fp32 [B, L, 3*H*64] -> the output as an fp16 [hi | lo] pair (out_lo may be NULL; row
+ * stride ld_out elements, 0 = H*64), lse, and -- if qkv_lp is not NULL -- the fp16 copy of q | k | v the backward kernels read. */
+int mudpt_attention_fwd_exact(const float* qkv32, void* qkv_lp, void* out_hi, void* out_lo, int32_t ld_out, float* lse, int32_t B, int32_t L,
+                              int32_t H, int32_t causal, void* stream);
 /* causal: bit 0 = causal mask.  Kernel choice (tests / A-B).  Default: padded length <= 96 (the text tower): the fused two-sweep pass over
  * resident Q, K, V, dO; longer non-causal sequences up to 224 (the vision tower): the single-sweep kernel (S, dP, exp computed once, dS
  * crosses LDS for dQ); otherwise the dQ kernel + dK/dV kernel pair (delta through `delta`).  bit 1 = force the two kernels, bit 3 = force the

@@ -9,9 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MUDPT_LIB") or os.path.join(HERE, "lib", "libmudpt_hip.so")  # MUDPT_LIB: A/B runs of two builds on one box
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "mudpt.h")
 
-BF16, F16 = 0, 1
+BF16, F16, F32 = 0, 1, 2  # F32: the exact mode (include/mudpt.h MUDPT_F32)
 VARIANT_MUDPT, VARIANT_COCOOP = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD, EPI_PATCH, EPI_STORE_F32 = range(6)
 
 
@@ -65,6 +65,7 @@ SIGNATURES = {
                                    _i32, _i32, _i32, _vp]),
     "mudpt_attention_padded_len": (_i32, [_i32]),
     "mudpt_attention_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mudpt_attention_fwd_exact": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mudpt_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mudpt_attention_fwd_single": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mudpt_attention_bwd_single": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -118,9 +118,10 @@ struct Attn {
             vec4 v, l;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float f = x[dt][r] * scale;
-                v[r] = (elem)f;
-                l[r] = (elem)(f - (float)v[r]);
+                elem hv, lv;
+                split_hi_lo(x[dt][r] * scale, hv, lv);
+                v[r] = hv;
+                l[r] = lv;
             }
             *(vec4*)(dst_row + 16 * dt + 4 * g) = v;
             *(vec4*)(lo_row + 16 * dt + 4 * g) = l;

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_single_kernel(AttnArgs p, const 
         const size_t oo = (size_t)b * ld_out + hd * 64 + ch * 8;
         vec8 hi, lo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { hi[j] = (elem)o[j]; lo[j] = (elem)(o[j] - (float)hi[j]); }
+        for (int j = 0; j < 8; ++j) { elem hv, lv; split_hi_lo(o[j], hv, lv); hi[j] = hv; lo[j] = lv; }
         *(vec8*)((elem*)out_sel + oo) = hi;
         if (out_lo) *(vec8*)((elem*)out_lo + oo) = lo;
     }

@@ -56,6 +56,19 @@ __device__ inline float quick_gelu_grad(float u) {
     return s * (1.0f + 1.702f * u * (1.0f - s));
 }
 
+// [hi | lo] pair of an fp32 value for a split-operand GEMM (Tower::split): hi = T(v), lo = T(v - hi), so that hi + lo carries 22 bits.
+// The value passes through an opaque register first: with -ffp-contract=fast (hipcc's default) the compiler may form `hi` from the
+// UNROUNDED product that made v (v_fma_mixlo_f16: one rounding) in one place and from the rounded v in another; on exact ties the two
+// disagree and hi + lo is then off by a whole ulp of T (measured in round 3: 1 element in ~8 000 of the exact attention output).
+template <typename E>
+__device__ inline void split_hi_lo(float v, E& hi, E& lo) {
+    asm volatile("" : "+v"(v));
+    hi = (E)v;
+    float h = (float)hi;
+    asm volatile("" : "+v"(h));
+    lo = (E)(v - h);
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

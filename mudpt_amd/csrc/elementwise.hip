@@ -71,6 +71,40 @@ int launch_patchify(int dtype, const float* images, void* patches, int B, int S,
     return MUDPT_OK;
 }
 
+// Split-operand form (exact mode): row = [hi | lo] of 2 ldk elements, lo = pixel - (float)hi; one thread per pixel slot.
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_split_kernel(const float* __restrict__ img, typename T::elem* __restrict__ out, int B, int S, int p, int ldk) {
+    using elem = typename T::elem;
+    const int g = S / p, K0 = 3 * p * p;
+    const size_t total = (size_t)B * g * g * ldk;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = idx % ldk;
+        const size_t patch = idx / ldk;
+        float v = 0.f;
+        if (k < K0) {
+            const int c = k / (p * p), py = (k / p) % p, px = k % p;
+            const int gx = patch % g, gy = (patch / g) % g;
+            const size_t b = patch / ((size_t)g * g);
+            v = img[((b * 3 + c) * S + gy * p + py) * S + gx * p + px];
+        }
+        elem hi, lo;
+        split_hi_lo(v, hi, lo);
+        out[patch * 2 * ldk + k] = hi;
+        out[patch * 2 * ldk + ldk + k] = lo;
+    }
+}
+
+int launch_patchify_split(int dtype, const float* images, void* patches, int B, int S, int p, int ldk, hipStream_t s) {
+    ARG_CHECK(images && patches && B > 0 && S > 0 && p > 0 && S % p == 0 && ldk >= 3 * p * p, "patchify: bad arguments S=%d p=%d ldk=%d", S, p, ldk);
+    const size_t total = (size_t)B * (S / p) * (S / p) * ldk;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(patchify_split_kernel<BF16>, dim3(grid), dim3(256), 0, s, images, (__bf16*)patches, B, S, p, ldk);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(patchify_split_kernel<F16>, dim3(grid), dim3(256), 0, s, images, (_Float16*)patches, B, S, p, ldk);
+    else { set_error("patchify: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
+    HIP_TRY(hipGetLastError());
+    return MUDPT_OK;
+}
+
 // ---- set_rows: x[b, row0 + i, :] = rows[i, :] (+ add[i, :])
 __global__ __launch_bounds__(256) void set_rows_kernel(float* __restrict__ x, int L, int d, int row0, int n, const float* __restrict__ rows,
                                                        const float* __restrict__ add) {

@@ -150,14 +150,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
                 *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = o;
             } else if constexpr (EPI == EPI_GELU) {
                 typename T::vec4 u = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
-                typename T::vec4 g = {(elem)quick_gelu(v[0]), (elem)quick_gelu(v[1]), (elem)quick_gelu(v[2]),
-                                      (elem)quick_gelu(v[3])};
                 *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = u;
-                *(typename T::vec4*)((elem*)p.out1 + orow * p.ldo1 + n) = g;
                 if (p.out1_lo) {  // split operand: the next GEMM contracts over [hi | lo] against [W | W]
-                    typename T::vec4 lo = {(elem)(quick_gelu(v[0]) - (float)g[0]), (elem)(quick_gelu(v[1]) - (float)g[1]),
-                                           (elem)(quick_gelu(v[2]) - (float)g[2]), (elem)(quick_gelu(v[3]) - (float)g[3])};
+                    typename T::vec4 g, lo;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { elem hv, lv; split_hi_lo(quick_gelu(v[c]), hv, lv); g[c] = hv; lo[c] = lv; }
+                    *(typename T::vec4*)((elem*)p.out1 + orow * p.ldo1 + n) = g;
                     *(typename T::vec4*)((elem*)p.out1_lo + orow * p.ldo1 + n) = lo;
+                } else {
+                    typename T::vec4 g = {(elem)quick_gelu(v[0]), (elem)quick_gelu(v[1]), (elem)quick_gelu(v[2]), (elem)quick_gelu(v[3])};
+                    *(typename T::vec4*)((elem*)p.out1 + orow * p.ldo1 + n) = g;
                 }
             } else if constexpr (EPI == EPI_RESIDUAL) {
                 const f32x4 r4 = *(const f32x4*)((const float*)p.aux + orow * p.ldaux + n);

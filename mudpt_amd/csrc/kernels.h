@@ -112,6 +112,9 @@ struct AttnArgs {
     // Honoured by the two-kernel form (whole sequence on chip, non-causal) and the tiled kernels; elsewhere everything is computed.
     int win_row0 = 0, win_n = 0;
     int B = 0, L = 0, H = 0; bool causal = false;
+    // exact-fp32 forward (attention_exact.hip): q | k | v in fp32 [B, L, 3*H*64] and, optionally, where to leave their T copy for the backward
+    const float* qkv32 = nullptr;
+    void* qkv_lp = nullptr;
 };
 // Single-query forms for the last block (attention_single.hip): ONE query row per sequence (token row a.sel_rows[b]) against all keys
 // (causal: the first pos + 1).  q_sel / dout_sel / dq_sel are compact [B, H*64]; out_sel has row stride ld_out (optional low half out_lo);
@@ -122,12 +125,17 @@ int launch_attn_bwd_single(int dtype, const AttnArgs& a, const void* q_sel, cons
 int attn_padded_len(int L);
 int launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);
 int launch_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);  // prof spans both kernels
+// Exact-fp32 forward (the "fp32" mode): reads a.qkv32, writes a.out (fp16 hi) + a.out_lo (fp16 lo, optional) + a.lse and, if a.qkv_lp
+// is set, the fp16 copy of q, k, v that the backward kernels read.
+int launch_attn_fwd_exact(const AttnArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // Small / HBM-bound helpers
 // ------------------------------------------------------------------------------------------------
 // images fp32 [B,3,H,W] -> patches T [B*P, ldk], columns 3*p*p.. zero  (im2col of the stride-p conv, clip/model.py:527-529)
 int launch_patchify(int dtype, const float* images, void* patches, int B, int image_size, int patch, int ldk, hipStream_t s);
+// the same as a split operand: row = [hi (ldk) | lo (ldk)], lo = pixel - hi (exact mode: the conv weight is stored [W | W])
+int launch_patchify_split(int dtype, const float* images, void* patches, int B, int image_size, int patch, int ldk, hipStream_t s);
 // x[b, row0 + i, :] = rows[i, :] (+ add[i, :])  for i < n : CLS row, prompt rows, deep-prompt splice.
 int launch_set_rows(float* x, int B, int L, int d, int row0, int n, const float* rows, const float* add, hipStream_t s);
 // dst[r] = src[rows[r]] (gather) / dst[rows[r]] = src[r] (scatter): whole rows of row_bytes (multiple of 16), strides in bytes.

@@ -67,11 +67,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs p) {
             if constexpr (OUT_F32) {
                 ((f32x4*)((float*)p.out + (size_t)r * p.ldo))[i] = y;
             } else {
-                typename T::vec4 o = {(elem)y[0], (elem)y[1], (elem)y[2], (elem)y[3]};
-                ((typename T::vec4*)((elem*)p.out + (size_t)r * p.ldo))[i] = o;
                 if (p.out_lo) {
-                    typename T::vec4 lo = {(elem)(y[0] - (float)o[0]), (elem)(y[1] - (float)o[1]), (elem)(y[2] - (float)o[2]), (elem)(y[3] - (float)o[3])};
+                    typename T::vec4 o, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { elem hv, lv; split_hi_lo(y[j], hv, lv); o[j] = hv; lo[j] = lv; }
+                    ((typename T::vec4*)((elem*)p.out + (size_t)r * p.ldo))[i] = o;
                     ((typename T::vec4*)((elem*)p.out_lo + (size_t)r * p.ldo))[i] = lo;
+                } else {
+                    typename T::vec4 o = {(elem)y[0], (elem)y[1], (elem)y[2], (elem)y[3]};
+                    ((typename T::vec4*)((elem*)p.out + (size_t)r * p.ldo))[i] = o;
                 }
             }
         }

@@ -82,6 +82,10 @@ struct Tower {
     std::vector<BlockAct> a;  // layers entries; the last block's output exists on the tail rows only (xout_sel)
     // scratch shared by all blocks
     void *h = nullptr, *g = nullptr;                    // T [M,d], T [M,4d]
+    // Exact mode (mudpt_config.dtype = MUDPT_F32): every forward GEMM runs on split operands (above) and the attention forward in fp32
+    // (attention_exact.hip): in_proj writes q | k | v in fp32 here, the attention kernel leaves the fp16 copy the backward reads.
+    bool exact = false;
+    float* qkv32 = nullptr;                             // fp32 [M, 3d] scratch (exact mode)
     float* dx = nullptr; void* dx_lp = nullptr;         // gradient residual stream fp32 + T copy
     void *dattn = nullptr, *dqkv = nullptr;             // T
     float* delta = nullptr;
@@ -127,6 +131,7 @@ using namespace mudpt;
 struct mudpt_model {
     mudpt_config cfg;
     int dtype = 0;
+    bool exact = false;  // mudpt_config.dtype == MUDPT_F32: fp16 split operands everywhere on the forward + fp32 attention forward
     std::vector<void*> allocs;
     std::vector<std::string> missing;  // weight keys not yet set
     bool prompts_set = false;
@@ -134,7 +139,7 @@ struct mudpt_model {
 
     Tower vis, txt;
     // vision stem / head
-    void* conv_w = nullptr;  // T [dv, 3 p p]
+    void* conv_w = nullptr;  // T [dv, 3 p p]   (exact mode: [W | W], rows of 2 K0, against [hi | lo] patch rows)
     float *cls = nullptr, *vpos = nullptr, *ln_pre_g = nullptr, *ln_pre_b = nullptr, *ln_post_g = nullptr, *ln_post_b = nullptr;
     float* vproj = nullptr;  // [dv, e]
     void* patches = nullptr; // T [B P, 3 p p]
@@ -281,7 +286,9 @@ static int attn_call(mudpt_model* m, const Tower& t, const AttnArgs& a0, bool bw
     // executed MFMA FLOPs: forward S = QK^T and PV (2 products of 2 L^2 64 each per head); backward 7 products (dQ sweep: S, dP, dQ;
     // dK/dV sweep: S, dP, dV, dK); the causal tower does about half of each
     const double prod = 2.0 * a.L * (double)a.L * 64.0 * a.H * a.B * (a.causal ? 0.5 : 1.0);
-    if (m->prof && !a.sel_rows) m->exec_flop += (bwd ? 7.0 : 2.0) * prod;
+    const bool exact_fwd = !bwd && a.qkv32;  // exact mode: fp32 matrix-core FLOPs are not counted as executed bf16 / fp16 MFMA work
+    if (m->prof && !a.sel_rows && !exact_fwd) m->exec_flop += (bwd ? 7.0 : 2.0) * prod;
+    if (exact_fwd) return launch_attn_fwd_exact(a, s);
     if (!prof_big(m, t, a.B * a.L) || a.sel_rows) return bwd ? launch_attn_bwd(m->dtype, a, s) : launch_attn_fwd(m->dtype, a, s);
     // algorithmic bytes: forward reads q, k, v and writes o (+ its low half in split mode); backward reads q, k, v, o, do and writes dq, dk, dv
     const double tok = (double)a.B * a.L * a.H * 128.0;
@@ -352,7 +359,7 @@ static int alloc_tower_weights(mudpt_model* m, Tower& t, int d, int layers, int 
 static size_t tower_bytes_per_row(const Tower& t) {
     const size_t d = t.d, sp = 2;  // split operands counted always (upper bound)
     const size_t per_layer = d * 4 * 2 + d * 3 * 2 + d * 2 * sp + d * 4 * 2 + 16 + (size_t)t.heads * 4 * 2;
-    const size_t shared = d * 2 * sp + d * 4 * 2 * sp + d * 4 + d * 2 + d * 2 + d * 3 * 2 + d * 4 + (size_t)t.heads * 4 * 2;
+    const size_t shared = d * 2 * sp + d * 4 * 2 * sp + d * 4 + d * 2 + d * 2 + d * 3 * 2 + d * 4 + (size_t)t.heads * 4 * 2 + (t.exact ? d * 3 * 4 : 0);
     return per_layer * t.layers + shared;
 }
 
@@ -385,6 +392,7 @@ static int alloc_tower_acts(mudpt_model* m, Tower& t, int L, int max_seq) {
     ALLOC_T(t.dattn, M * d * 2); ALLOC_T(t.dqkv, M * 3 * d * 2);
     ALLOC_T(t.delta, (size_t)max_seq * heads * t.Lp * 4);
     ALLOC_T(t.upd, M * d * 4);
+    if (t.exact) ALLOC_T(t.qkv32, M * 3 * d * 4);
     const size_t S = (size_t)max_seq;
     ALLOC_T(t.xin_sel, S * d * 4); ALLOC_T(t.xmid_sel, S * d * 4); ALLOC_T(t.xout_sel, S * d * 4);
     ALLOC_T(t.attn_sel, S * d * 2 * sp); ALLOC_T(t.h_sel, S * d * 2 * sp); ALLOC_T(t.u_sel, S * 4 * d * 2); ALLOC_T(t.g_sel, S * 4 * d * 2 * sp); ALLOC_T(t.dattn_sel, S * d * 2);
@@ -409,7 +417,7 @@ extern "C" const char* mudpt_last_error(void) { return get_error(); }
 
 extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     ARG_CHECK(c && out, "create: null argument");
-    ARG_CHECK(c->dtype == MUDPT_BF16 || c->dtype == MUDPT_F16, "create: dtype must be MUDPT_BF16 or MUDPT_F16");
+    ARG_CHECK(c->dtype == MUDPT_BF16 || c->dtype == MUDPT_F16 || c->dtype == MUDPT_F32, "create: dtype must be MUDPT_BF16, MUDPT_F16 or MUDPT_F32");
     ARG_CHECK(c->variant == MUDPT_VARIANT_MUDPT || c->variant == MUDPT_VARIANT_COCOOP, "create: unknown variant %d", c->variant);
     const bool cocoop = c->variant == MUDPT_VARIANT_COCOOP;
     ARG_CHECK(cocoop || c->depth > 0, "PROMPT_DEPTH should be > 0");  // trainers/mudpt.py:52
@@ -425,7 +433,11 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
 
     mudpt_model* m = new mudpt_model();
     m->cfg = *c;
-    m->dtype = c->dtype;
+    // MUDPT_F32 ("exact"): the kernels' operand type is fp16, every forward operand a [hi | lo] pair (22 bits), attention forward in fp32
+    m->exact = c->dtype == MUDPT_F32;
+    m->dtype = m->exact ? (int)MUDPT_F16 : c->dtype;
+    m->vis.exact = m->txt.exact = m->exact;
+    if (m->exact) m->last_single = false;  // the single-query kernels of the last block take fp16 q, k, v: the general (exact) forward runs instead
     m->lp_grad = (c->dtype == MUDPT_BF16);
     m->lp_upd = (c->dtype == MUDPT_BF16);
     m->cocoop = cocoop;
@@ -434,19 +446,20 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     const int dv = c->v_width, dt = c->t_width, e = c->embed_dim, n = c->n_ctx, D1 = m->cfg.depth - 1, B = c->max_batch, C = c->n_cls;
     const int TS = cocoop ? B * C : C;  // text sequences per step: one per (image, class) pair in CoCoOp (trainers/cocoop.py:187-194)
     auto fail = [&](int code) { mudpt_destroy(m); return code; };
-    if (int r = alloc_tower_weights(m, m->vis, dv, c->v_layers, c->v_heads, false, cocoop ? Lv : Lv - n, false)) return fail(r);
+    if (int r = alloc_tower_weights(m, m->vis, dv, c->v_layers, c->v_heads, false, cocoop ? Lv : Lv - n, m->exact)) return fail(r);
     if (int r = alloc_tower_acts(m, m->vis, Lv, B)) return fail(r);
     // the text tower's activations are sized by mudpt_set_class_prompts: its trimmed length (max(eot) + 1 of ctx_len positions) and, for
     // CoCoOp, the number of images whose B * C prompts fit the memory budget at once are only known there
-    if (int r = alloc_tower_weights(m, m->txt, dt, c->t_layers, c->t_heads, true, 1, c->dtype == MUDPT_F16)) return fail(r);
+    if (int r = alloc_tower_weights(m, m->txt, dt, c->t_layers, c->t_heads, true, 1, m->dtype == MUDPT_F16)) return fail(r);
     m->txt.L = c->ctx_len; m->txt.Lp = attn_padded_len(c->ctx_len);
     auto body = [&]() -> int {
         const int K0 = (3 * c->patch * c->patch + 63) / 64 * 64;  // conv-as-GEMM K, zero-padded to the GEMM's granularity (ViT-L/14: 588 -> 640)
-        ALLOC(m->conv_w, (size_t)dv * K0 * 2);
+        const size_t xs = m->exact ? 2 : 1;  // exact mode: [hi | lo] patch rows against [W | W]
+        ALLOC(m->conv_w, (size_t)dv * K0 * 2 * xs);
         ALLOC(m->cls, dv * 4); ALLOC(m->vpos, (size_t)(1 + P) * dv * 4);
         ALLOC(m->ln_pre_g, dv * 4); ALLOC(m->ln_pre_b, dv * 4); ALLOC(m->ln_post_g, dv * 4); ALLOC(m->ln_post_b, dv * 4);
         ALLOC(m->vproj, (size_t)dv * e * 4);
-        ALLOC(m->patches, (size_t)B * P * K0 * 2);
+        ALLOC(m->patches, (size_t)B * P * K0 * 2 * xs);
         ALLOC(m->xpre, (size_t)B * Lv * dv * 4); ALLOC(m->pre_mean, (size_t)B * Lv * 4); ALLOC(m->pre_rstd, (size_t)B * Lv * 4);
         ALLOC(m->f_ln, (size_t)B * dv * 4); ALLOC(m->post_mean, B * 4); ALLOC(m->post_rstd, B * 4); ALLOC(m->df_ln, (size_t)B * dv * 4);
         ALLOC(m->cls_rows, B * 4); ALLOC(m->vprompt_rows, (size_t)B * n * 4);
@@ -600,7 +613,7 @@ extern "C" int mudpt_set_weight(mudpt_model* m, const char* key, const float* da
         const size_t k0 = (size_t)3 * c.patch * c.patch, k0p = (k0 + 63) / 64 * 64;
         std::vector<float> padded(dv * k0p, 0.f);  // rows zero-padded like the im2col rows
         for (size_t r = 0; r < dv; ++r) memcpy(&padded[r * k0p], data + r * k0, k0 * 4);
-        rc = upload_lp(m->dtype, m->conv_w, nullptr, padded.data(), dv, k0p);
+        rc = m->exact ? upload_lp_dup(m->dtype, m->conv_w, padded.data(), dv, k0p) : upload_lp(m->dtype, m->conv_w, nullptr, padded.data(), dv, k0p);
     }
     else if (k == "visual.class_embedding") { EXPECT(dv); rc = upload_f32(m->cls, data, numel); }
     else if (k == "visual.positional_embedding") { EXPECT((1 + P) * dv); rc = upload_f32(m->vpos, data, numel); }
@@ -900,11 +913,13 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
         return block_fwd_tail(m, t, nseq, s, true);
     }
     GemmArgs q; q.A = t.h; q.lda = sp * d; q.B = t.split ? w.w_in2 : w.w_in; q.ldb = sp * d; q.M = M; q.N = 3 * d; q.K = sp * d; q.bias = w.b_in; q.out0 = a.qkv; q.ldo0 = 3 * d;
-    TRY(gemm_call(m, EPI_STORE, q, s));
+    if (t.exact) q.out0 = t.qkv32;  // fp32 q | k | v for the exact attention forward, which leaves their fp16 copy in a.qkv for the backward
+    TRY(gemm_call(m, t.exact ? EPI_STORE_F32 : EPI_STORE, q, s));
     for (const Tower::Seg& g : segs) {
         AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * sp * d * esz; at.lse = a.lse + g.lse0;
         at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
         if (t.split) { at.ld_out = 2 * d; at.out_lo = (char*)at.out + (size_t)d * esz; }
+        if (t.exact) { at.qkv32 = t.qkv32 + (size_t)g.row0 * 3 * d; at.qkv_lp = (char*)a.qkv + (size_t)g.row0 * 3 * d * esz; }
         TRY(attn_call(m, t, at, false, s));
     }
     if (i + 1 == t.layers) return block_fwd_tail(m, t, nseq, s);
@@ -1047,8 +1062,10 @@ static int vision_forward(mudpt_model* m, const float* images, int B, hipStream_
     const int dv = c.v_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1;
     const int P = (c.image_size / c.patch) * (c.image_size / c.patch), Lv = m->vis.L, K0 = (3 * c.patch * c.patch + 63) / 64 * 64;
     float* Pm = m->params;
-    TRY(launch_patchify(m->dtype, images, m->patches, B, c.image_size, c.patch, K0, s));
-    GemmArgs pe; pe.A = m->patches; pe.lda = K0; pe.B = m->conv_w; pe.ldb = K0; pe.M = B * P; pe.N = dv; pe.K = K0; pe.out0 = m->xpre; pe.ldo0 = dv;
+    const int xs = m->exact ? 2 : 1;  // exact mode: pixels as [hi | lo] pairs (an fp16 pixel alone carries 2.4e-4 of rounding into block 0)
+    if (m->exact) TRY(launch_patchify_split(m->dtype, images, m->patches, B, c.image_size, c.patch, K0, s));
+    else TRY(launch_patchify(m->dtype, images, m->patches, B, c.image_size, c.patch, K0, s));
+    GemmArgs pe; pe.A = m->patches; pe.lda = xs * K0; pe.B = m->conv_w; pe.ldb = xs * K0; pe.M = B * P; pe.N = dv; pe.K = xs * K0; pe.out0 = m->xpre; pe.ldo0 = dv;
     pe.patches = P; pe.seq_len = Lv; pe.pos = m->vpos;
     TRY(gemm_call(m, EPI_PATCH, pe, s));
     TRY(launch_set_rows(m->xpre, B, Lv, dv, 0, 1, m->cls, m->vpos, s));
@@ -1530,14 +1547,14 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
     if (!strcmp(name, "attn_fused_w1")) { m->attn_fused_w1 = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "split_k")) { m->split_k = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "attn_window")) { m->attn_window = value != 0; return MUDPT_OK; }
-    if (!strcmp(name, "last_single")) { m->last_single = value != 0; return MUDPT_OK; }
+    if (!strcmp(name, "last_single")) { m->last_single = value != 0 && !m->exact; return MUDPT_OK; }
     if (!strcmp(name, "txt_bucket_cost")) { m->txt_bucket_cost = value > 0 ? value : 0; m->prompts_set = false; return MUDPT_OK; }
     if (!strcmp(name, "txt_buckets")) { m->txt_buckets = value > 1 ? value : 1; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
     if (!strcmp(name, "prof_stride")) { m->prof_stride = value > 1 ? value : 1; return MUDPT_OK; }
     if (!strcmp(name, "cocoop_chunk")) { m->cocoop_chunk = value; m->prompts_set = false; return MUDPT_OK; }  // likewise
     if (!strcmp(name, "txt_split")) {  // the [W | W] copies are made while the weights are ingested: decide before the first mudpt_set_weight
         if (m->any_weight_set) { set_error("model_set: txt_split must be set before the first mudpt_set_weight"); return MUDPT_ERR_STATE; }
-        m->txt.split = value != 0 && m->dtype == MUDPT_F16;
+        m->txt.split = (value != 0 && m->dtype == MUDPT_F16) || m->exact;
         return MUDPT_OK;
     }
     set_error("model_set: unknown knob '%s'", name);
@@ -1696,6 +1713,11 @@ extern "C" int mudpt_attention_padded_len(int32_t L) { return attn_padded_len(L)
 extern "C" int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream) {
     AttnArgs a; a.qkv = qkv; a.out = out; a.lse = lse; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;
     return launch_attn_fwd(dtype, a, (hipStream_t)stream);
+}
+extern "C" int mudpt_attention_fwd_exact(const float* qkv32, void* qkv_lp, void* out_hi, void* out_lo, int32_t ld_out, float* lse, int32_t B, int32_t L, int32_t H,
+                                         int32_t causal, void* stream) {
+    AttnArgs a; a.qkv32 = qkv32; a.qkv_lp = qkv_lp; a.out = out_hi; a.out_lo = out_lo; a.ld_out = ld_out; a.lse = lse; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;
+    return launch_attn_fwd_exact(a, (hipStream_t)stream);
 }
 extern "C" int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int32_t B,
                                    int32_t L, int32_t H, int32_t causal, void* stream) {

@@ -74,7 +74,7 @@ class CustomCLIP(nn.Module):
         self.variant = variant
         cfg = capi.Config(shape.image_size, shape.patch, shape.v_width, shape.v_layers, shape.v_heads, shape.t_width,
                           shape.t_layers, shape.t_heads, shape.ctx_len, shape.embed_dim, shape.n_ctx, shape.depth,
-                          self.n_cls, self.max_batch, {"bf16": capi.BF16, "fp16": capi.F16}[dtype],
+                          self.n_cls, self.max_batch, {"bf16": capi.BF16, "fp16": capi.F16, "fp32": capi.F32}[dtype],
                           {"mudpt": capi.VARIANT_MUDPT, "cocoop": capi.VARIANT_COCOOP}[variant])
         torch.cuda.set_device(self.device)
         h = C.c_void_p()
