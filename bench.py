@@ -2,6 +2,7 @@
 """Headline benchmark: MuDPT ViT-B/16 forward+backward(+SGD step) images/s, batch 256 per MI355X, bf16.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # N > 1 with WORLD_SIZE unset: starts N fresh child processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -71,6 +72,83 @@ PEAK_HBM_GBS = 8000.0  # HBM3E spec (MI355X_MICROARCH.md; ~6300 GB/s achievable 
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_bytes_per_step.json")  # tools/prof_join.py output of the same command (PMC passes)
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start N fresh child processes of this same command line, one per
+    GPU -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1 -- and wait for them.  This parent has
+    not touched the GPU (no HIP call, no torch.cuda.is_available()) and never replaces itself: the children are ordinary subprocesses.
+    Rank 0's stdout (the ONE JSON line) is this process's stdout.  Replaces nn.DataParallel's single-process fan-out
+    (trainers/mudpt.py:230-233) at the bench level."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:  # a dead rank leaves its peers in a collective: end them (exact PIDs we started)
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def stub_worker(args, rank: int, world: int):
+    """MUDPT_BENCH_STUB=1: the launcher / rendezvous / timing / JSON contract of the N > 1 path with a stand-in step (a CPU bucket of the
+    real size, one all-reduce per step over gloo): what tests/test_bench_launcher_cpu.py drives, no GPU and no library involved.  The
+    line it prints says "data": "stub" and carries no roofline: it is not a measurement."""
+    import torch.distributed as dist
+    if os.environ.get("MUDPT_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)  # test hook: a rank that dies before the rendezvous
+    if world > 1:
+        dist.init_process_group("gloo")
+    bucket = torch.full((1243136,), float(rank + 1))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        if world > 1:
+            dist.all_reduce(bucket)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bucket.fill_(float(rank + 1))
+        if world > 1:
+            dist.all_reduce(bucket)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert bucket[0].item() == world * (world + 1) / 2, "all-reduce(sum) over the ranks"
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec fwd+bwd ViT-B/16 MuDPT", "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "images/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "stub",
+                          "config": {"workload": "launcher rehearsal: stand-in step, NOT a measurement", "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+                          "collective": {"backend": "gloo" if world > 1 else None, "world_size": world, "bucket_bytes": bucket.numel() * 4}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,11 +176,15 @@ def main():
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the short fp16 (parity configuration) timing appended to the bf16 line")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))  # the bare command: this process only starts and reaps the ranks
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
+    if os.environ.get("MUDPT_BENCH_STUB"):
+        return stub_worker(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the MuDPT path has no CPU fallback")
     if os.environ.get("MUDPT_BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo collectives
