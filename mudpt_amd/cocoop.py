@@ -9,12 +9,10 @@ Same class name, registry name, hooks and error behaviour: ``check_cfg`` (:203),
 """
 from __future__ import annotations
 
-import os.path as osp
-
 from . import parallel, synth
 from .model import CustomCLIP, ModelShape
-from .trainer import (TRAINER_REGISTRY, TrainerX, build_lr_scheduler, build_optimizer, data_parallel_step, load_checkpoint,
-                      load_clip_state_dict, load_pretrained_weights, precision_to_dtype, tokenize_prompts)
+from .trainer import (TRAINER_REGISTRY, TrainerX, build_lr_scheduler, build_optimizer, data_parallel_step, install_loader, load_clip_state_dict,
+                      load_plugin_checkpoint, load_pretrained_weights, parse_batch, precision_to_dtype, save_on_main, tokenize_prompts)
 
 
 @TRAINER_REGISTRY.register()
@@ -70,43 +68,18 @@ class CoCoOp(TrainerX):
         self.scaler = None  # loss scaling lives inside the library
         if parallel.world_size() > 1:  # the reference's nn.DataParallel (:244-247) becomes one process per GPU
             parallel.broadcast_params(self.model.flat_params)
-        from .prefetch import DevicePrefetcher  # the next batch's host -> device copy overlaps the current step
-        if getattr(self, "train_loader_x", None) is not None and not isinstance(self.train_loader_x, DevicePrefetcher):
-            self.train_loader_x = DevicePrefetcher(self.train_loader_x, device=f"cuda:{local}")
+        install_loader(self, local)  # rank-aware (world > 1) and prefetched training loader
 
     def forward_backward(self, batch):
         # loss = model(image, label) (cross-entropy inside forward, :196-197) + backward in one library call
         return data_parallel_step(self, batch)
 
     def parse_batch_train(self, batch):
-        input = batch["img"]
-        label = batch["label"]
-        if not batch.get("_mudpt_sharded", False):  # batches from the DevicePrefetcher are already sliced and on the device
-            input, label = parallel.shard_batch(input, label)  # N > 1: this rank's slice, as nn.DataParallel's scatter (:244-247)
-        input = input.to(self.device)
-        label = label.to(self.device)
-        return input, label
+        return parse_batch(self, batch)
 
     def save_model(self, *args, **kwargs):
-        if parallel.is_main():
-            super().save_model(*args, **kwargs)
+        save_on_main(self, super().save_model, *args, **kwargs)
 
     def load_model(self, directory, epoch=None):
-        if not directory:
-            print("Note that load_model() is skipped as no Pretrained model is given")
-            return
-        names = self.get_model_names()
-        model_file = "model-best.pth.tar"  # by default, the best model is loaded
-        if epoch is not None:
-            model_file = "model.pth.tar-" + str(epoch)
-        for name in names:
-            model_path = osp.join(directory, name, model_file)
-            if not osp.exists(model_path):
-                raise FileNotFoundError('Model not found at "{}"'.format(model_path))
-            checkpoint = load_checkpoint(model_path)
-            state_dict = checkpoint["state_dict"]
-            epoch = checkpoint["epoch"]
-            for k in ("token_prefix", "token_suffix"):  # ignore fixed token vectors (:303-307)
-                state_dict.pop(k, None)
-            print("Loading weights to {} " 'from "{}" (epoch = {})'.format(name, model_path, epoch))
-            self._models[name].load_state_dict(state_dict, strict=False)
+        load_plugin_checkpoint(self, directory, epoch, ("token_prefix", "token_suffix"),  # trainers/cocoop.py:303-307
+                               "Note that load_model() is skipped as no Pretrained model is given")

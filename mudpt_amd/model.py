@@ -130,6 +130,7 @@ class CustomCLIP(nn.Module):
             self._cp_feat, self._cp_dfeat = (capi.device_view(q.value, n.value, self.device).view(self.n_cls, shape.embed_dim) for q in (f, df))
         self._loss = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._text_version = None  # flat_params._version the library's cached text features belong to
+        self.loss_scale = 128.0    # the library's default (mudpt_set_loss_scale)
 
     # -- initialisation of the trainables, trainers/mudpt.py:57-81 and clip/model.py:512-519 ---------------------
     def _init_trainables(self, emb_w, ctx_token_ids, seed):
@@ -214,14 +215,16 @@ class CustomCLIP(nn.Module):
         """Sum of a [n_cls, embed] table over the ranks of the class-parallel group (rows of other ranks are zero in the feature table,
         so the sum is the gather, bit for bit, also for uneven shards)."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        # only a class-SHARDED handle exchanges: on an unsharded one every rank holds the full table already, and summing world
+        # identical copies would scale d(features) -- and with it every text-side gradient -- by world without any error
+        if self.class_shard is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             return dist.all_reduce(table, group=self.group, async_op=async_op)
         return None
 
     def forward_backward_cp(self, image: torch.Tensor, label: torch.Tensor, grad_scale: float = 1.0, return_logits: bool = False):
         """The training step in class-parallel phases (include/mudpt.h): towers forward with this rank's classes -> sum of the feature
         table -> head over the local images and all classes -> sum of d(features), overlapped with the vision backward -> text backward
-        over this rank's classes.  Also valid on an unsharded handle / one rank (no exchange happens)."""
+        over this rank's classes.  On an unsharded handle (every rank encodes all classes) the phases run without any exchange."""
         self._check_images(image)
         assert label.shape == (image.shape[0],), f"labels must be [B], got {tuple(label.shape)}"
         image = image.to(self.device, torch.float32).contiguous()
@@ -254,6 +257,12 @@ class CustomCLIP(nn.Module):
                                                    capi.ptr(self._loss), capi.ptr(logits), self._stream()), "forward_backward")
         self._text_version = self.flat_params._version  # the step's forward left this version's text features in the library
         return (self._loss[0], logits) if return_logits else self._loss[0]
+
+    def set_loss_scale(self, scale: float):
+        """Static scale of the backward pass (include/mudpt.h mudpt_set_loss_scale; default 128 per sample); the trainer plugins move it
+        like torch's GradScaler does (halve on overflow, grow back after a run of clean steps)."""
+        capi.check(self.lib.mudpt_set_loss_scale(self._h, float(scale)), "set_loss_scale")
+        self.loss_scale = float(scale)
 
     def sgd_step(self, lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, dampening: float = 0.0, nesterov: bool = False):
         capi.check(self.lib.mudpt_sgd_step(self._h, lr, momentum, weight_decay, dampening, int(nesterov), self._stream()), "sgd_step")

@@ -97,6 +97,67 @@ def shard_batch(image: torch.Tensor, label: torch.Tensor):
     return image[idx.start:idx.stop], label[idx.start:idx.stop]
 
 
+def step_consensus(loss: torch.Tensor, flat_grads: torch.Tensor):
+    """What every rank must agree on after the bucket all-reduce, in ONE 3-element all-reduce (sum): (loss finite on every rank,
+    gradients finite on every rank, the GLOBAL-batch mean loss).  The reference's nn.DataParallel gathers the logits, so its
+    ``F.cross_entropy`` and the ``loss.item()`` it logs are over the whole global batch (trainers/mudpt.py:249-256): the logged value here
+    is the sum over ranks of loss_local / world, not the local slice's mean.  A rank that raised alone would leave the others hanging
+    in the next collective, hence the consensus flags (Dassl's detect_anomaly checks the loss before backward)."""
+    lf, gf = torch.isfinite(loss).all(), torch.isfinite(flat_grads).all()
+    v = torch.stack([(~lf).float(), (~gf).float(), torch.where(lf, loss.detach().float().reshape(()) * grad_scale(), torch.zeros((), device=loss.device))]).to(flat_grads.device)
+    if world_size() > 1:
+        import torch.distributed as dist
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    v = v.tolist()  # the step's one host sync (the reference's loss.item(), trainers/mudpt.py:254)
+    return v[0] == 0, v[1] == 0, v[2]
+
+
+class ShardedBatchSampler:
+    """This rank's contiguous 1/world slice of every index batch of a loader's own batch sampler.  Every rank iterates the SAME
+    global batch sampler (equal seeds: Dassl seeds torch / numpy / random from cfg.SEED on every rank), so the slices of a step are
+    disjoint and their concatenation over the ranks is exactly the single-process batch, in the single-process order: what
+    nn.DataParallel's scatter of ONE loaded batch gives (trainers/mudpt.py:230-233) -- but each rank only reads and decodes its own
+    images."""
+
+    def __init__(self, batch_sampler, rank: int, world: int):
+        self.batch_sampler, self.rank, self.world = batch_sampler, rank, world
+
+    def __iter__(self):
+        for idx in self.batch_sampler:
+            idx = list(idx)
+            if len(idx) % self.world != 0:
+                raise ValueError(f"global batch {len(idx)} is not divisible by the {self.world} data-parallel ranks")
+            r = shard(len(idx), self.rank, self.world)
+            yield idx[r.start:r.stop]
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+
+def shard_loader(loader, r: int | None = None, world: int | None = None):
+    """A rank-aware copy of a torch DataLoader (same dataset, workers, collate function; batch sampler wrapped in
+    ShardedBatchSampler), or None when ``loader`` is not a DataLoader with a batch sampler (list-like synthetic loaders, iterable
+    datasets): the caller then falls back to slicing the loaded global batch (``shard_batch``)."""
+    from torch.utils.data import DataLoader
+    r = rank() if r is None else r
+    world = world_size() if world is None else world
+    if world == 1:
+        return loader
+    if not isinstance(loader, DataLoader) or getattr(loader, "batch_sampler", None) is None:
+        return None
+    kw = dict(num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, timeout=loader.timeout,
+              worker_init_fn=loader.worker_init_fn, generator=loader.generator)
+    if loader.num_workers > 0:
+        kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=loader.persistent_workers)
+    return DataLoader(loader.dataset, batch_sampler=ShardedBatchSampler(loader.batch_sampler, r, world), **kw)
+
+
+def barrier():
+    if world_size() > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
 def all_finite(loss: torch.Tensor, flat_grads: torch.Tensor) -> bool:
     """Consensus form of Dassl's non-finite-loss check (``detect_anomaly``): a rank that raised alone would leave the others
     hanging in the next collective, so the flag is reduced (MIN) and every rank takes the same branch."""

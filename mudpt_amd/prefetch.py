@@ -24,8 +24,9 @@ _END = object()
 class DevicePrefetcher:
     DEPTH = 2  # batches staged ahead of the one the trainer is working on
 
-    def __init__(self, loader, device=None, keys=("img", "label")):
+    def __init__(self, loader, device=None, keys=("img", "label"), shard=True):
         self.loader, self.keys = loader, tuple(keys)
+        self.shard = shard  # False: the loader is rank-aware already (parallel.shard_loader), its batches are this rank's slices
         self.device = torch.device(device) if device is not None else (torch.device("cuda") if torch.cuda.is_available() else None)
         self.enabled = self.device is not None and self.device.type == "cuda" and torch.cuda.is_available()
         self.stream = torch.cuda.Stream(self.device) if self.enabled else None
@@ -43,7 +44,7 @@ class DevicePrefetcher:
         """This rank's slice of the batch on the device (copy enqueued on the side stream), other entries untouched."""
         if not all(k in batch for k in self.keys):
             return batch, None
-        img, label = parallel.shard_batch(batch[self.keys[0]], batch[self.keys[1]])
+        img, label = parallel.shard_batch(batch[self.keys[0]], batch[self.keys[1]]) if self.shard else (batch[self.keys[0]], batch[self.keys[1]])
         out = dict(batch)
         out["_mudpt_sharded"] = True
         with torch.cuda.stream(self.stream):
@@ -81,7 +82,16 @@ class DevicePrefetcher:
                     raise item
                 batch, ev = item
                 if ev is not None:
-                    torch.cuda.current_stream(self.device).wait_event(ev)  # the step's kernels wait for the copy, the host does not
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)  # the step's kernels wait for the copy, the host does not
+                    # The staged tensors were allocated on the side stream: tell the caching allocator that the consumer's stream uses
+                    # them, or a batch dropped without a host sync could hand its block back to the side-stream pool -- and to the NEXT
+                    # batch's copy -- while a conversion / patch-gather kernel of this step still reads it (a uint8 or fp16 loader, a
+                    # caller that does not sync on the loss).
+                    for k in self.keys:
+                        t = batch.get(k)
+                        if isinstance(t, torch.Tensor) and t.is_cuda:
+                            t.record_stream(cur)
                 yield batch
         finally:
             stop.set()

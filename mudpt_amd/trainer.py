@@ -65,21 +65,108 @@ def tokenize_prompts(prompts, ctx_len=77, near=None):
             raise RuntimeError(f"no BPE merge table available for prompt {e}: {no_vocab}") from None
 
 
+LOSS_SCALE_INIT, LOSS_SCALE_MIN, LOSS_SCALE_GROWTH_INTERVAL = 128.0, 1.0, 2000
+
+
 def data_parallel_step(trainer, batch):
     """One training step of either plugin (trainers/mudpt.py:235-261, trainers/cocoop.py:246-276) in data-parallel form:
     forward + cross-entropy + backward in ONE library call on this rank's images (gradient of loss / world), ONE all-reduce of the
-    flat bucket, the non-finite check on what every rank sees, then the optimizer step -- so replicas stay bitwise identical."""
+    flat bucket, the consensus on what every rank sees (parallel.step_consensus), then the optimizer step -- so replicas stay bitwise
+    identical.  The logged loss is the GLOBAL-batch mean, as the reference's (nn.DataParallel gathers the logits before
+    F.cross_entropy, trainers/mudpt.py:249-256).
+
+    Loss scaling follows torch.cuda.amp.GradScaler (the reference's amp path, trainers/mudpt.py:228,239-246): the backward runs on
+    per-sample gradients times a power-of-two scale inside the library; gradients that come back non-finite (an fp16 copy of a token
+    gradient overflowed) make every rank SKIP the optimizer step and halve the scale; LOSS_SCALE_GROWTH_INTERVAL clean steps in a row
+    double it again, up to the initial value.  A non-finite LOSS is an error, as in Dassl's model_backward_and_update."""
     image, label = trainer.parse_batch_train(batch)
-    loss = trainer.model.forward_backward(image, label, grad_scale=parallel.grad_scale())
-    parallel.allreduce_grads(trainer.model.flat_grads)
-    if not parallel.all_finite(loss, trainer.model.flat_grads):  # Dassl's model_backward_and_update checks the loss before backward
+    model = trainer.model
+    loss = model.forward_backward(image, label, grad_scale=parallel.grad_scale())
+    parallel.allreduce_grads(model.flat_grads)
+    loss_ok, grads_ok, global_loss = parallel.step_consensus(loss, model.flat_grads)
+    if not loss_ok:
         raise FloatingPointError("Loss is infinite or NaN!")
-    trainer.optim.step()
-    trainer.model.invalidate_text_cache()  # the optimizer wrote through .data views of the bucket
-    loss_summary = {"loss": loss.item()}  # the reference logs the local value too (trainers/mudpt.py:253-256)
+    state = trainer.__dict__.setdefault("_loss_scale_state", {"scale": getattr(model, "loss_scale", LOSS_SCALE_INIT), "clean": 0, "skipped": 0})
+    if grads_ok:
+        trainer.optim.step()
+        model.invalidate_text_cache()  # the optimizer wrote through .data views of the bucket
+        state["clean"] += 1
+        if state["clean"] >= LOSS_SCALE_GROWTH_INTERVAL and state["scale"] < LOSS_SCALE_INIT and hasattr(model, "set_loss_scale"):
+            state["scale"], state["clean"] = state["scale"] * 2.0, 0
+            model.set_loss_scale(state["scale"])
+    else:
+        if state["scale"] <= LOSS_SCALE_MIN or not hasattr(model, "set_loss_scale"):
+            raise FloatingPointError("Gradients are infinite or NaN at the smallest loss scale!")
+        state["scale"], state["clean"], state["skipped"] = state["scale"] * 0.5, 0, state["skipped"] + 1
+        model.set_loss_scale(state["scale"])
+        print(f"Gradient overflow: step skipped, loss scale halved to {state['scale']:g}")
+    loss_summary = {"loss": global_loss}
     if (trainer.batch_idx + 1) == trainer.num_batches:
         trainer.update_lr()
     return loss_summary
+
+
+def install_loader(trainer, local: int):
+    """Rank-aware, prefetched training loader (called at the end of build_model).  world > 1: ``train_loader_x`` is rebuilt over the same
+    dataset with its batch sampler wrapped in parallel.ShardedBatchSampler, so each rank loads and decodes 1/world of every global
+    batch (the reference's nn.DataParallel scatters ONE loaded batch, trainers/mudpt.py:230-233; here nothing is loaded N times);
+    loaders that cannot be rebuilt (list-like synthetic ones) keep the slice-after-load fallback (parallel.shard_batch).  Then the
+    DevicePrefetcher overlaps the next batch's host -> device copy with the current step."""
+    from .prefetch import DevicePrefetcher
+    loader = getattr(trainer, "train_loader_x", None)
+    trainer._loader_sharded = False
+    if loader is None or isinstance(loader, DevicePrefetcher):
+        return
+    if parallel.world_size() > 1:
+        sharded = parallel.shard_loader(loader)
+        if sharded is not None:
+            loader, trainer._loader_sharded = sharded, True
+    trainer.train_loader_x = DevicePrefetcher(loader, device=f"cuda:{local}", shard=not trainer._loader_sharded)
+
+
+def parse_batch(trainer, batch):
+    """parse_batch_train of both plugins (trainers/mudpt.py:263-268, trainers/cocoop.py:278-283).  N > 1: this rank's share of the global
+    batch -- already the whole batch when the loader is rank-aware or the batch came through the DevicePrefetcher (sliced, on the
+    device: the two .to(device) are then no-ops), else the contiguous slice nn.DataParallel's scatter would give this GPU, taken on the
+    host so that only 1/world of the images crosses PCIe."""
+    input, label = batch["img"], batch["label"]
+    if not batch.get("_mudpt_sharded", False) and not getattr(trainer, "_loader_sharded", False):
+        input, label = parallel.shard_batch(input, label)
+    return input.to(trainer.device), label.to(trainer.device)
+
+
+def save_on_main(trainer, save, *args, **kwargs):
+    """Replicas are identical: rank 0 alone writes OUTPUT_DIR; the others wait until the file is complete, so that a load_model that
+    follows (Dassl's after_train with TEST.FINAL_MODEL = best_val, a resume) never reads a missing or half-written checkpoint."""
+    try:
+        if parallel.is_main():
+            save(*args, **kwargs)
+    finally:
+        parallel.barrier()
+
+
+def load_plugin_checkpoint(trainer, directory, epoch, drop_keys, skipped_note):
+    """load_model of both plugins (trainers/mudpt.py:270-302, trainers/cocoop.py:285-307): {directory}/{name}/model.pth.tar-{epoch} or
+    model-best.pth.tar, keys state_dict / epoch, the fixed token buffers dropped, strict=False (the frozen backbone entries of a
+    reference checkpoint are ignored)."""
+    if not directory:
+        print(skipped_note)
+        return
+    names = trainer.get_model_names()
+    model_file = "model-best.pth.tar"  # by default, the best model is loaded
+    if epoch is not None:
+        model_file = "model.pth.tar-" + str(epoch)
+    for name in names:
+        model_path = osp.join(directory, name, model_file)
+        if not osp.exists(model_path):
+            raise FileNotFoundError('Model not found at "{}"'.format(model_path))
+        checkpoint = load_checkpoint(model_path)
+        state_dict = checkpoint["state_dict"]
+        epoch = checkpoint["epoch"]
+        for k in drop_keys:  # ignore fixed token vectors
+            state_dict.pop(k, None)
+        print("Loading weights to {} " 'from "{}" (epoch = {})'.format(name, model_path, epoch))
+        trainer._models[name].load_state_dict(state_dict, strict=False)
 
 
 def class_parallel_shard(n_cls: int, setting=None):
@@ -169,48 +256,17 @@ class MuDPT(TrainerX):
         # the reference wraps in nn.DataParallel when device_count > 1 (:230-233); here: one process per GPU
         if parallel.world_size() > 1:
             parallel.broadcast_params(self.model.flat_params)
-        # overlap the next batch's host -> device copy with the current step (the reference copies synchronously at the top of each step)
-        from .prefetch import DevicePrefetcher
-        if getattr(self, "train_loader_x", None) is not None and not isinstance(self.train_loader_x, DevicePrefetcher):
-            self.train_loader_x = DevicePrefetcher(self.train_loader_x, device=f"cuda:{local}")
+        install_loader(self, local)  # rank-aware (world > 1) and prefetched training loader
 
     def forward_backward(self, batch):
         return data_parallel_step(self, batch)
 
     def parse_batch_train(self, batch):
-        input = batch["img"]
-        label = batch["label"]
-        # N > 1: this rank's contiguous slice of the global batch, as nn.DataParallel's scatter (trainers/mudpt.py:230-233); the slice
-        # is taken on the host so only 1/world of the images crosses PCIe.  Batches that come through the DevicePrefetcher are already
-        # sliced and on the device (their copy overlapped the previous step): the two .to(device) below are then no-ops.
-        if not batch.get("_mudpt_sharded", False):
-            input, label = parallel.shard_batch(input, label)
-        input = input.to(self.device)
-        label = label.to(self.device)
-        return input, label
+        return parse_batch(self, batch)
 
     def save_model(self, *args, **kwargs):
-        if parallel.is_main():  # replicas are identical: one writer per OUTPUT_DIR
-            super().save_model(*args, **kwargs)
+        save_on_main(self, super().save_model, *args, **kwargs)
 
     def load_model(self, directory, epoch=None):
-        if not directory:
-            print("Note that load_model() is skipped as no pretrained model is given")
-            return
-        names = self.get_model_names()
-        model_file = "model-best.pth.tar"  # by default, the best model is loaded
-        if epoch is not None:
-            model_file = "model.pth.tar-" + str(epoch)
-        for name in names:
-            model_path = osp.join(directory, name, model_file)
-            if not osp.exists(model_path):
-                raise FileNotFoundError('Model not found at "{}"'.format(model_path))
-            checkpoint = load_checkpoint(model_path)
-            state_dict = checkpoint["state_dict"]
-            epoch = checkpoint["epoch"]
-            # ignore fixed token vectors (trainers/mudpt.py:293-298); the frozen backbone entries of a reference
-            # checkpoint are ignored by strict=False
-            for k in ("mudpt_prompt_learner.token_prefix", "mudpt_prompt_learner.token_suffix"):
-                state_dict.pop(k, None)
-            print("Loading weights to {} " 'from "{}" (epoch = {})'.format(name, model_path, epoch))
-            self._models[name].load_state_dict(state_dict, strict=False)
+        load_plugin_checkpoint(self, directory, epoch, ("mudpt_prompt_learner.token_prefix", "mudpt_prompt_learner.token_suffix"),  # trainers/mudpt.py:293-298
+                               "Note that load_model() is skipped as no pretrained model is given")

@@ -188,3 +188,160 @@ def test_class_parallel_setting(monkeypatch):
     assert trainer.class_parallel_shard(1000, "off") is None
     monkeypatch.setenv("MUDPT_CLASS_PARALLEL", "0")
     assert trainer.class_parallel_shard(1000, None) is None
+
+
+class _ToyDataset(torch.utils.data.Dataset):
+    """Dassl's DatasetWrapper in miniature: item i -> {"img", "label", "index"}; `reads` records which items THIS process decoded."""
+
+    def __init__(self, n, size):
+        g = torch.Generator().manual_seed(7)
+        self.x, self.y, self.reads = torch.randn(n, 3, size, size, generator=g), torch.randint(0, 11, (n,), generator=g), []
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, i):
+        self.reads.append(int(i))
+        return {"img": self.x[i], "label": self.y[i], "index": i}
+
+
+def _toy_loader(ds, batch):
+    torch.manual_seed(321)  # Dassl's set_random_seed(cfg.SEED): the same on every rank, so RandomSampler draws the same permutation
+    return torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=True, drop_last=True, num_workers=0)
+
+
+def _loader_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from mudpt_amd import parallel, trainer
+    parallel.init("gloo")
+    case = GoldenCase("mudpt_tiny")
+    ds = _ToyDataset(16, case.cfg.image_size)
+    t = object.__new__(trainer.MuDPT)
+    t.model = _OracleModel(case, case.params)
+    t.optim = torch.optim.SGD(t.model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    t.device, t.batch_idx, t.num_batches = torch.device("cpu"), 0, 99
+    t.train_loader_x = _toy_loader(ds, 4)
+    trainer.install_loader(t, rank)  # what build_model does last
+    assert t._loader_sharded and len(t.train_loader_x) == 4
+    seen, losses = [], []
+    for batch in t.train_loader_x:
+        assert batch["img"].shape[0] == 4 // world  # this rank's share only
+        seen.append(batch["index"].tolist())
+        losses.append(t.forward_backward(batch)["loss"])
+    assert sorted(ds.reads) == sorted(i for b in seen for i in b)  # nothing beyond this rank's share was read / decoded
+    assert t.model.calls == [((4 // world, 3, case.cfg.image_size, case.cfg.image_size), 1.0 / world)] * 4
+    torch.save({"seen": seen, "losses": losses, "params": t.model.flat_params.clone()}, f"{out}.r{rank}")
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rank_aware_loader_splits_every_global_batch(tmp_path):
+    """world 2: each rank's rebuilt loader (parallel.shard_loader, installed by build_model) yields disjoint halves of every global batch;
+    their union over the ranks is the single-process batch, in the single-process order; the plugin's steps on them equal the
+    single-process run; and the logged loss is the GLOBAL-batch mean (nn.DataParallel gathers the logits, trainers/mudpt.py:249-256)."""
+    from mudpt_amd import trainer
+    out = str(tmp_path / "ld")
+    mp.spawn(_loader_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".r0"), torch.load(out + ".r1")
+    case = GoldenCase("mudpt_tiny")
+    ds = _ToyDataset(16, case.cfg.image_size)
+    t = object.__new__(trainer.MuDPT)
+    t.model = _OracleModel(case, case.params)
+    t.optim = torch.optim.SGD(t.model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    t.device, t.batch_idx, t.num_batches = torch.device("cpu"), 0, 99
+    single, losses = [], []
+    for batch in _toy_loader(ds, 4):
+        single.append(batch["index"].tolist())
+        losses.append(t.forward_backward(batch)["loss"])
+    assert [a + b for a, b in zip(r0["seen"], r1["seen"])] == single  # rank 0's half then rank 1's = the single-process batch
+    assert all(set(a).isdisjoint(b) for a, b in zip(r0["seen"], r1["seen"]))
+    assert r0["losses"] == r1["losses"]  # every rank logs the same (global) value
+    torch.testing.assert_close(torch.tensor(r0["losses"]), torch.tensor(losses), atol=2e-6, rtol=1e-5)
+    assert torch.equal(r0["params"], r1["params"])
+    torch.testing.assert_close(r0["params"], t.model.flat_params, atol=2e-6, rtol=1e-5)
+
+
+def test_shard_loader_falls_back_for_list_like_loaders():
+    from mudpt_amd import parallel
+    ds = _ToyDataset(8, 4)
+    assert parallel.shard_loader([{"img": 0}], 0, 2) is None          # dassl_lite's synthetic manager: slice after load instead
+    ld = torch.utils.data.DataLoader(ds, batch_size=4)
+    assert parallel.shard_loader(ld, 0, 1) is ld                      # one process: untouched
+    halves = [list(parallel.shard_loader(ld, r, 2).batch_sampler) for r in range(2)]
+    assert halves == [[[0, 1], [4, 5]], [[2, 3], [6, 7]]]
+    with pytest.raises(ValueError, match="not divisible"):
+        list(parallel.shard_loader(torch.utils.data.DataLoader(ds, batch_size=3), 0, 2).batch_sampler)
+
+
+class _OverflowModel(torch.nn.Module):
+    """forward_backward writes inf into the bucket on chosen steps: what an overflowed fp16 token gradient does to the real library."""
+
+    def __init__(self, bad_steps):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.ones(4))
+        self.flat_params, self.flat_grads = self.w.data, torch.zeros(4)
+        self.w.grad = self.flat_grads
+        self.bad, self.n, self.loss_scale, self.scales = set(bad_steps), 0, 128.0, []
+
+    def forward_backward(self, image, label, grad_scale=1.0):
+        self.flat_grads.fill_(float("inf") if self.n in self.bad else 1.0)
+        self.n += 1
+        return torch.tensor(0.5)
+
+    def set_loss_scale(self, s):
+        self.loss_scale = s
+        self.scales.append(s)
+
+    def invalidate_text_cache(self):
+        pass
+
+
+def test_overflow_skips_the_step_and_halves_the_loss_scale(monkeypatch):
+    """GradScaler semantics (the reference's amp path, trainers/mudpt.py:228,243-246): non-finite gradients -> no optimizer step, scale
+    halved; a run of clean steps doubles it again up to the initial value; a non-finite LOSS is an error (Dassl's detect_anomaly)."""
+    from mudpt_amd import trainer
+    monkeypatch.setattr(trainer, "LOSS_SCALE_GROWTH_INTERVAL", 3)
+    t = object.__new__(trainer.MuDPT)
+    t.model = _OverflowModel({1, 2})
+    t.optim = torch.optim.SGD(t.model.parameters(), lr=0.1)
+    t.device, t.batch_idx, t.num_batches = torch.device("cpu"), 0, 99
+    batch = {"img": torch.zeros(2, 3, 4, 4), "label": torch.zeros(2, dtype=torch.long)}
+    w = []
+    for _ in range(9):
+        assert t.forward_backward(batch) == {"loss": 0.5}
+        w.append(t.model.w[0].item())
+    # steps 1 and 2 overflow: parameters unchanged there, the scale goes 128 -> 64 -> 32, then two growth intervals bring it back
+    assert w[0] == pytest.approx(0.9) and w[1] == w[0] and w[2] == w[0] and w[3] == pytest.approx(0.8)
+    assert t.model.scales == [64.0, 32.0, 64.0, 128.0] and t._loss_scale_state["skipped"] == 2
+    t.model.forward_backward = lambda *a, **k: torch.tensor(float("nan"))
+    with pytest.raises(FloatingPointError, match="Loss is infinite or NaN"):
+        t.forward_backward(batch)
+    t2 = object.__new__(trainer.MuDPT)
+    t2.model = _OverflowModel(set(range(100)))
+    t2.optim = torch.optim.SGD(t2.model.parameters(), lr=0.1)
+    t2.device, t2.batch_idx, t2.num_batches = torch.device("cpu"), 0, 99
+    with pytest.raises(FloatingPointError, match="smallest loss scale"):
+        for _ in range(20):
+            t2.forward_backward(batch)
+    assert t2.model.loss_scale == 1.0 and t2.model.w[0].item() == 1.0  # never stepped on garbage
+
+
+def test_unsharded_handle_never_exchanges(monkeypatch):
+    """world > 1 with every rank encoding ALL classes (class_shard None): the class-parallel phases must not sum the (identical) tables --
+    d(features) would come out world times too large without any error."""
+    import torch.distributed as dist
+    from mudpt_amd.model import CustomCLIP
+    m = object.__new__(CustomCLIP)
+    torch.nn.Module.__init__(m)
+    m.class_shard, m.group = None, None
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    called = []
+    monkeypatch.setattr(dist, "all_reduce", lambda *a, **k: called.append(1))
+    assert m._exchange(torch.zeros(3)) is None and not called
+    m.class_shard = (0, 5)
+    m._exchange(torch.zeros(3))
+    assert called == [1]

@@ -170,3 +170,30 @@ def test_prefetched_epoch_equals_the_plain_loop(tmp_path):
     assert torch.equal(a.model.flat_params, b.model.flat_params)
     a.model.close()
     b.model.close()
+
+
+def test_prefetcher_keeps_staged_batches_alive_for_the_consumer_stream():
+    """A loader that yields fp16 images (CustomCLIP then converts on the consumer's stream) and a caller that drops every batch WITHOUT a
+    host sync: the staged tensors were allocated on the prefetcher's side stream, so without record_stream the caching allocator could
+    give a dropped batch's block to the next batch's copy while the conversion / patch gather still reads it.  Logits through the
+    prefetcher must equal the unprefetched path for every batch."""
+    from mudpt_amd.prefetch import DevicePrefetcher
+    from tests.helpers import GoldenCase
+    from tests.test_model_gpu import build
+    case = GoldenCase("mudpt_tiny")
+    g = torch.Generator().manual_seed(5)
+    S = case.cfg.image_size
+    batches = [{"img": torch.randn(3, 3, S, S, generator=g).half(), "label": torch.randint(0, 11, (3,), generator=g)} for _ in range(12)]
+    m = build(case, "fp16")
+    m.eval()
+    want = [m(b["img"].float().cuda()).clone() for b in batches]
+    torch.cuda.synchronize()
+    got = []
+    for batch in DevicePrefetcher(batches, device="cuda:0"):
+        assert batch["img"].is_cuda and batch["img"].dtype == torch.float16
+        got.append(m(batch["img"]))  # no sync, no reference kept to the staged batch beyond this iteration
+        del batch
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    m.close()
