@@ -196,6 +196,10 @@ int mudpt_gemm(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K,
                const void* B, int32_t ldb, const float* bias, void* out0, int32_t ldo0, void* out1, int32_t ldo1,
                const void* aux, int32_t ldaux, int32_t patches, int32_t seq_len, const float* pos, int32_t variant, void* stream);
 /* variant: kernel-choice knob for tests / tuning (0 = the default dispatch). */
+/* The c_fc GEMM of a split-operand tower (MUDPT_F32, and the text tower under MUDPT_F16): u = A . B^T + bias (T), QuickGELU(u) as the
+ * [hi | lo] pair g_hi + g_lo (both T, row stride ldg) that the c_proj GEMM contracts against [W | W]. */
+int mudpt_gemm_gelu_split(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb, const float* bias,
+                          void* u, int32_t ldu, void* g_hi, void* g_lo, int32_t ldg, void* stream);
 int mudpt_layernorm_fwd(int32_t dtype, const float* x, int32_t ldx, const int32_t* row_index, const float* gamma,
                         const float* beta, void* out, int32_t ldo, int32_t out_f32, float* mean, float* rstd,
                         int32_t rows, int32_t d, void* stream);

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mudpt_profile_read_classes": (_i32, [_vp, C.POINTER(C.c_double * 5), C.POINTER(C.c_double * 5), C.POINTER(C.c_int64 * 5), C.POINTER(C.c_double)]),
     "mudpt_gemm": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32,
                           _i32, _i32, _vp, _i32, _vp]),
+    "mudpt_gemm_gelu_split": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "mudpt_layernorm_fwd": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "mudpt_layernorm_bwd": (_i32, [_i32, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
                                    _i32, _i32, _i32, _vp]),

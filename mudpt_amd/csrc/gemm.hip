@@ -272,7 +272,7 @@ static int split_k_slices(int epi, const GemmArgs& a, const GemmOpts& o) {
 bool gemm_uses_pp(int epi, const GemmArgs& a, int variant) {
     const bool pp_epi = epi == EPI_STORE || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32;
     const int v = variant & 0xff;
-    return (v == 0 || v == 3 || v == 5 || v == 6) && pp_epi && !a.out1_lo && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
+    return (v == 0 || v == 3 || v == 5 || v == 6) && pp_epi && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
            (epi != EPI_GELU_BWD || a.ldaux % 8 == 0);
 }
 

@@ -41,6 +41,8 @@ __device__ inline void vmcnt() {
 // sc1 / sc0 sc1 stores are 8-60 % SLOWER (fc 315 -> 515 us: the L2 no longer absorbs the store bursts), nt stores and nt aux loads
 // are within +-1 % over the 8 GEMMs of a block.  Counters with nt stores over the whole step (round 2, separate --pmc passes): fc's HBM-side reads 412 -> 332 MB per launch, but its
 // writes 632 -> 900 MB (partial lines are no longer combined in the L2) and the step 25.10 -> 25.38 ms.  Plain policy everywhere; the parameters stay for the next experiment.
+constexpr int EPI_GELU_SPLIT = 100;  // EPI_GELU with out1 as a split operand: out1 = hi(gelu(u)), out1_lo = the remainder (exact mode, Tower::split)
+
 template <typename T, int EPI, int ST = 0, int LD = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int ntiles, int rem_half) {
     using elem = typename T::elem;
@@ -67,15 +69,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((size_t)p.N * p.ldb * 2 < 0xffffffffull ? (size_t)p.N * p.ldb * 2 : 0xffffffffull), 0x00020000);
 
     // epilogue operands through bounds-checked descriptors as well (out-of-range lanes get offset OOB: dropped / read 0)
-    static_assert(EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_GELU_BWD || EPI == EPI_STORE_F32, "epilogue not built for gemm_pp");
+    static_assert(EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_BWD || EPI == EPI_STORE_F32, "epilogue not built for gemm_pp");
+    constexpr bool GELU = (EPI == EPI_GELU || EPI == EPI_GELU_SPLIT);
     constexpr int OOB = (int)0x80000000;
     constexpr bool OUT_F32 = (EPI == EPI_STORE_F32);
     // B fragment rows: permuted (a lane ends up with 16 consecutive columns = 32 bytes of T) for the T outputs, natural
     // (4 consecutive columns per sub-tile = 16 bytes of fp32) for the fp32 output; see the epilogue.
     constexpr bool NAT = OUT_F32;
-    constexpr int NST = (EPI == EPI_STORE || EPI == EPI_GELU_BWD) ? 16 : 32;  // stores per wave per tile, exact
+    constexpr int NST = (EPI == EPI_STORE || EPI == EPI_GELU_BWD) ? 16 : (EPI == EPI_GELU_SPLIT ? 48 : 32);  // stores per wave per tile, exact
     const auto rsOut0 = __builtin_amdgcn_make_buffer_rsrc(p.out0, 0, p.M * p.ldo0 * (OUT_F32 ? 4 : 2), 0x00020000);
-    const auto rsOut1 = __builtin_amdgcn_make_buffer_rsrc(p.out1, 0, EPI == EPI_GELU ? p.M * p.ldo1 * 2 : 0, 0x00020000);
+    const auto rsOut1 = __builtin_amdgcn_make_buffer_rsrc(p.out1, 0, GELU ? p.M * p.ldo1 * 2 : 0, 0x00020000);
+    const auto rsOut1Lo = __builtin_amdgcn_make_buffer_rsrc(p.out1_lo, 0, EPI == EPI_GELU_SPLIT ? p.M * p.ldo1 * 2 : 0, 0x00020000);
     const auto rsAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0, EPI == EPI_GELU_BWD ? p.M * p.ldaux * 2 : 0, 0x00020000);
     const auto rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
     bool epi_pending = false;  // the previous step ended with an epilogue: NST stores sit in the VMEM queue
@@ -289,6 +293,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut1, off1, 0, ST);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut1, off1, 16, ST);
                     }
+                    if constexpr (EPI == EPI_GELU_SPLIT) {
+                        vec8 l0, l1;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            elem hv, lv;
+                            split_hi_lo(quick_gelu(acc[i][0][c]), hv, lv); o0[c] = hv; l0[c] = lv;
+                            split_hi_lo(quick_gelu(acc[i][1][c]), hv, lv); o0[4 + c] = hv; l0[4 + c] = lv;
+                            split_hi_lo(quick_gelu(acc[i][2][c]), hv, lv); o1[c] = hv; l1[c] = lv;
+                            split_hi_lo(quick_gelu(acc[i][3][c]), hv, lv); o1[4 + c] = hv; l1[4 + c] = lv;
+                        }
+                        const int off1 = row_off(i, p.ldo1, 2, n);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut1, off1, 0, ST);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut1, off1, 16, ST);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l0), rsOut1Lo, off1, 0, ST);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l1), rsOut1Lo, off1, 16, ST);
+                    }
                 }
                 }
 #pragma unroll
@@ -412,7 +432,7 @@ template <typename T>
 static int launch_pp_t(int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
     switch (epi) {
         case EPI_STORE: return launch_pp<T, EPI_STORE>(a, s, o);
-        case EPI_GELU: return launch_pp<T, EPI_GELU>(a, s, o);
+        case EPI_GELU: return a.out1_lo ? launch_pp<T, EPI_GELU_SPLIT>(a, s, o) : launch_pp<T, EPI_GELU>(a, s, o);
         case EPI_GELU_BWD: return launch_pp<T, EPI_GELU_BWD>(a, s, o);
         case EPI_STORE_F32: return launch_pp<T, EPI_STORE_F32>(a, s, o);
     }
@@ -424,6 +444,7 @@ static int launch_pp_t(int epi, const GemmArgs& a, hipStream_t s, const GemmOpts
 int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
     ARG_CHECK((size_t)a.M * a.lda * 2 < 0xffffffffull && (size_t)a.N * a.ldb * 2 < 0xffffffffull, "gemm_pp: operand larger than 4 GiB");
     ARG_CHECK(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldo0 % 8 == 0, "gemm_pp: strides must be multiples of 8");
+    ARG_CHECK(!a.out1_lo || (uintptr_t)a.out1_lo % 16 == 0, "gemm_pp: out1_lo must be 16-byte aligned");
     // epilogue offsets are 32-bit and rely on the descriptors' range check for rows >= M
     ARG_CHECK((size_t)a.M * a.ldo0 * (epi == EPI_STORE_F32 ? 4 : 2) < 0x7fffffffull && (size_t)a.M * (size_t)(a.ldo1 > a.ldaux ? a.ldo1 : a.ldaux) * 2 < 0x7fffffffull, "gemm_pp: output larger than 2 GiB");
     if (dtype == DT_BF16) return launch_pp_t<BF16>(epi, a, s, o);

@@ -1646,6 +1646,11 @@ extern "C" int mudpt_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int3
     a.aux = aux; a.ldaux = ldaux; a.patches = patches; a.seq_len = seq_len; a.pos = pos;
     return launch_gemm(dtype, epi, a, (hipStream_t)stream, o);
 }
+extern "C" int mudpt_gemm_gelu_split(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb, const float* bias,
+                                     void* u, int32_t ldu, void* g_hi, void* g_lo, int32_t ldg, void* stream) {
+    GemmArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias; a.out0 = u; a.ldo0 = ldu; a.out1 = g_hi; a.out1_lo = g_lo; a.ldo1 = ldg;
+    return launch_gemm(dtype, EPI_GELU, a, (hipStream_t)stream);
+}
 extern "C" int mudpt_layernorm_fwd(int32_t dtype, const float* x, int32_t ldx, const int32_t* row_index, const float* gamma, const float* beta, void* out,
                                    int32_t ldo, int32_t out_f32, float* mean, float* rstd, int32_t rows, int32_t d, void* stream) {
     LnFwdArgs a; a.x = x; a.ldx = ldx; a.row_index = row_index; a.gamma = gamma; a.beta = beta; a.out = out; a.ldo = ldo; a.out_f32 = out_f32 != 0;

@@ -127,3 +127,30 @@ def test_cocoop_logits_at_scale_100_within_1e_3(name):
         assert torch.isfinite(g).all()
         assert torch.nn.functional.cosine_similarity(g.detach().cpu().flatten(), r.flatten(), dim=0).item() > 0.995, k
     m.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(804, 3072, 768), (6000, 3072, 1536), (22000, 2048, 1024)])
+def test_split_gelu_epilogue(M, N, K):
+    """c_fc of a split-operand tower: u (fp16) and QuickGELU(u) as a [hi | lo] pair, through the small-tile kernel (M 804) and the persistent
+    kernel (its EPI_GELU_SPLIT epilogue: 48 stores per wave and tile), K = 2 x width as in the exact mode.  hi + lo must carry the fp32
+    value of QuickGELU(acc + bias) to 2^-21; u is its fp16 rounding."""
+    from mudpt_amd import capi
+    lib = capi.load()
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g)).cuda().half()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).cuda().half()
+    bias = torch.randn(N, generator=g).cuda()
+    u = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+    gg = torch.zeros(M, 2 * N, device="cuda", dtype=torch.float16)  # [hi | lo] rows
+    rc = lib.mudpt_gemm_gelu_split(1, M, N, K, P(A), K, P(W), K, P(bias), P(u), N, P(gg), C.c_void_p(gg.data_ptr() + 2 * N), 2 * N, None)
+    assert rc == 0, lib.mudpt_last_error().decode()
+    torch.cuda.synchronize()
+    acc = (A.double() @ W.double().t() + bias.double()).cpu()
+    ref = acc * torch.sigmoid(1.702 * acc)
+    got = gg[:, :N].double().cpu() + gg[:, N:].double().cpu()
+    # fp32 accumulation of K products + the hardware exp / rcp of QuickGELU (1 ulp each): ~1e-6 relative; the pair itself 2^-22
+    err = (got - ref).abs().max().item()
+    print(f"split GELU {M}x{N}x{K}: max err {err:.2e} (max |g| {ref.abs().max():.2f})")
+    assert err <= 3e-6 * max(1.0, ref.abs().max().item())
+    assert (u.double().cpu() - acc).abs().max().item() <= 2.0 ** -11 * acc.abs().max().item() + 1e-6
+    assert (gg[:, :N].float() - (gg[:, :N].float() + gg[:, N:].float())).abs().max().item() <= 2.0 ** -11 * gg[:, :N].float().abs().max().item()

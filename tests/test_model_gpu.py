@@ -18,7 +18,11 @@ pytestmark = pytest.mark.gpu
 LOGIT_RMS = {"fp16": 5e-4, "bf16": 1.6e-2}
 LOGIT_ATOL = {"fp16": 1e-3, "bf16": 3.2e-2}
 TINY_SLACK = 1.5
-GRAD_RTOL = {"fp16": 2e-2, "bf16": 1.5e-1}  # relative to each gradient tensor's RMS
+GRAD_RTOL = {"fp16": 2e-2, "bf16": 1.5e-1}  # relative to each gradient tensor's RMS: single elements may be off by 4x this
+# RMS of the error over a whole gradient tensor, relative to the tensor's RMS (the error model of tests/test_cocoop_gpu.py without the
+# cancellation factor: MuDPT's gradients are sums of same-signed-on-average terms).  Measured on MI355X (round 3): fp16 <= 2.6e-3,
+# bf16 <= 2.4e-2 over the four fixtures; the bounds leave a factor ~2.
+GRAD_RMS = {"fp16": 6e-3, "bf16": 5e-2}
 
 
 def build(case: GoldenCase, dtype: str, max_batch=None, knobs=None):
@@ -100,8 +104,10 @@ def test_loss_and_grads_match_reference(case, dtype):
         r, g = ref[k], got[k]
         rms = r.pow(2).mean().sqrt().item()
         err = (g - r).abs().max().item()
-        print(f"{dtype} {k}: rms {rms:.3e} max err {err:.3e}")
+        rel_rms = (g - r).pow(2).mean().sqrt().item() / max(rms, 1e-30)
+        print(f"{dtype} {k}: rms {rms:.3e} max err {err:.3e} rms err {rel_rms:.3e} x rms")
         assert err <= GRAD_RTOL[dtype] * rms * 4 + 1e-9, (k, err, rms)
+        assert rel_rms <= GRAD_RMS[dtype] or rms == 0, (k, rel_rms)
         # direction: cosine similarity of the whole tensor
         cos = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
         assert cos > (0.9995 if dtype == "fp16" else 0.99), (k, cos)

@@ -64,6 +64,21 @@ def test_scale100_fixture_matches_reference(name):
             torch.testing.assert_close(g[::8, ::8], sample, atol=1e-3 * scale + 1e-9, rtol=1e-4)
 
 
+def test_c1000_oracle_fixture_is_current():
+    """tests/golden/oracle_vitb16_c1000_b2.npz holds the ORACLE's own outputs at C = 1000 (the GPU suite compares against it instead of
+    recomputing them: 65 s).  Re-derive its logits here (forward only, ~15 s) so that a change to the oracle cannot leave it stale."""
+    import os
+    from tests.golden import gen_oracle_c1000 as G
+    cfg, frozen, tok, params, images, labels = G.inputs()
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vitb16_c1000_b2.npz"), allow_pickle=False)
+    assert int(z["tokens_checksum"]) == int(tok.sum())
+    with torch.no_grad():
+        logits = O.forward(cfg, frozen, params, frozen["token_embedding.weight"][tok], tok.argmax(-1), images)
+    torch.testing.assert_close(logits, torch.from_numpy(z["logits"]), atol=1e-6, rtol=1e-6)
+    loss = torch.nn.functional.cross_entropy(logits, labels).item()
+    assert abs(loss - float(z["loss"])) < 1e-6
+
+
 def test_block_outputs_match_reference(case):
     taps = {}
     with torch.no_grad():

@@ -197,3 +197,35 @@ def test_prefetcher_keeps_staged_batches_alive_for_the_consumer_stream():
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     m.close()
+
+
+def test_gradient_overflow_skips_the_step_and_halves_the_loss_scale(tmp_path):
+    """The backward runs on per-sample gradients times a power-of-two loss scale inside the library (include/mudpt.h mudpt_set_loss_scale).
+    With an absurd scale the fp16 copies of the token gradients overflow: the gradients come back non-finite, the plugin skips the
+    optimizer step and halves the scale (torch.cuda.amp.GradScaler's rule, the reference's amp path trainers/mudpt.py:228,243-246) until
+    a step goes through -- and the parameters never move on garbage."""
+    from mudpt_amd import dassl_lite, trainer  # noqa: F401
+    cfg = dassl_lite.default_cfg()
+    cfg.OUTPUT_DIR = str(tmp_path)
+    cfg.OPTIM.MAX_EPOCH, cfg.OPTIM.WARMUP_EPOCH, cfg.OPTIM.LR = 1, 0, 0.01
+    cfg.DATASET.NUM_TRAIN, cfg.DATASET.NUM_TEST = 8, 4
+    cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.DATALOADER.TEST.BATCH_SIZE = 4, 4
+    cfg.TRAINER.MUDPT.N_CTX, cfg.TRAINER.MUDPT.DEEP_PROMPT_DEPTH, cfg.TRAINER.MUDPT.PREC = 4, 12, "fp16"
+    t = dassl_lite.build_trainer(cfg)
+    batch = t.train_loader_x[0]
+    t.batch_idx, t.num_batches = 0, 99
+    ref_loss = t.forward_backward(batch)["loss"]              # a clean step at the default scale
+    t.model.set_loss_scale(2.0 ** 40)
+    t._loss_scale_state = {"scale": 2.0 ** 40, "clean": 0, "skipped": 0}
+    before = t.model.flat_params.clone()
+    skipped = 0
+    for _ in range(60):
+        out = t.forward_backward(batch)
+        assert out["loss"] == out["loss"]                      # the LOSS stays finite: only the scaled backward overflowed
+        if not torch.equal(t.model.flat_params, before):
+            break
+        skipped += 1
+    assert 1 <= skipped < 60 and t._loss_scale_state["skipped"] == skipped
+    assert t.model.loss_scale == 2.0 ** (40 - skipped) and torch.isfinite(t.model.flat_params).all() and torch.isfinite(t.model.flat_grads).all()
+    assert abs(out["loss"] - ref_loss) < 0.5                    # and training continues from where it was
+    t.model.close()
