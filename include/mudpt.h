@@ -219,7 +219,7 @@ int mudpt_attention_fwd_exact(const float* qkv32, void* qkv_lp, void* out_hi, vo
  * crosses LDS for dQ); otherwise the dQ kernel + dK/dV kernel pair (delta through `delta`).  bit 1 = force the two kernels, bit 3 = force the
  * fused two-sweep pass, bit 2 = the same with two 16-row blocks per wave, bit 4 = force the single sweep (non-causal, L <= 224).
  * Window form (block 0 of a tower needs its input gradient on the prompt rows only): bits 20-27 = n > 0 wanted rows per sequence starting
- * at row bits 8-19.  The 16-row blocks (L > 224: 64-row groups) holding a wanted row are computed exactly as without the window; all other
+ * at row bits 8-19.  The 16-row blocks (L > 224: 128-row groups) holding a wanted row are computed exactly as without the window; all other
  * rows of dqkv are left unwritten. */
 int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                         float* delta, void* dqkv, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream);

@@ -895,88 +895,103 @@ __global__ __launch_bounds__(NC * 128) void attn_bwd_sweep_kernel(AttnArgs p, co
 
 // ------------------------------------------------------------------------------------------------
 // Long sequences (L > 224: ViT-L/14@336 has 577 + n_ctx vision tokens, BASELINE configs[4]): the other operand no longer
-// fits in LDS as a whole, so it streams through a 64-row stage and the forward keeps a running (online) softmax.  Same
-// fragment conventions and inner products as the whole-sequence kernels above; one workgroup = 4 waves = 64 rows of the
-// "lane" operand.  Written for coverage of that configuration, not tuned.
+// fits in LDS next to everything else, so it streams through 64-row stages and the forward keeps a running (online) softmax.  Same
+// fragment conventions and inner products as the whole-sequence kernels above.  One workgroup = 8 waves = 128 rows of the "lane"
+// operand (round 3; 4 waves / 64 rows before: every stage of the streamed operand now feeds twice the MFMAs).  The stages are double
+// buffered: the global loads of stage st + 1 are issued before stage st is computed and written to the other LDS buffer after it
+// (registers carry them across the compute), so a stage costs ONE barrier and no exposed memory round trip (two barriers and a
+// synchronous global -> LDS copy per stage before).
 // ------------------------------------------------------------------------------------------------
+constexpr int TW = 8, TROWS = TW * 16;  // waves per workgroup, rows of the lane operand per workgroup
+
 template <typename T>
-__device__ inline void stage64(typename T::elem* img0, const typename T::elem* src0, size_t ld0, typename T::elem* img1, const typename T::elem* src1,
-                               size_t ld1, int row0, int L, int tid) {
+struct Stage64 {  // one 64-row stage of two [.., 64]-wide operands: 64 rows x 8 chunks x 2 images over 512 threads = one chunk of each per thread
     using vec8 = typename T::vec8;
     using elem = typename T::elem;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {  // 64 rows x 8 chunks per image over 256 threads
-        const int idx = tid + k * 256, row = idx >> 3, ch = idx & 7;
-        vec8 a, b;
+    vec8 a, b;
+    __device__ inline void load(const elem* src0, size_t ld0, const elem* src1, size_t ld1, int row0, int L, int tid) {
+        const int row = tid >> 3, ch = tid & 7;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { a[i] = (elem)0.f; b[i] = (elem)0.f; }
         if (row0 + row < L) {
             a = *(const vec8*)(src0 + (size_t)(row0 + row) * ld0 + ch * 8);
             b = *(const vec8*)(src1 + (size_t)(row0 + row) * ld1 + ch * 8);
         }
+    }
+    __device__ inline void write(elem* img0, elem* img1, int tid) const {
+        const int row = tid >> 3, ch = tid & 7;
         *(vec8*)(img0 + row * RS + ((ch ^ (row & 7)) << 3)) = a;
         *(vec8*)(img1 + row * RS + ((ch ^ (row & 7)) << 3)) = b;
     }
-}
+};
 
 template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(AttnArgs p, int nsb) {
+__global__ __launch_bounds__(TW * 64) void attn_fwd_tiled_kernel(AttnArgs p, int nsb) {
     using A = Attn<T>;
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
-    __shared__ __attribute__((aligned(16))) elem Ks[64 * RS];
-    __shared__ __attribute__((aligned(16))) elem Vs[64 * RS];
+    __shared__ __attribute__((aligned(16))) elem Ks[2][64 * RS];
+    __shared__ __attribute__((aligned(16))) elem Vs[2][64 * RS];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = blockIdx.x / nsb, sb = blockIdx.x - pair * nsb, b = pair / p.H, hd = pair - b * p.H;
     const int HD = p.H * 64, L = p.L, Lp = attn_padded_len_dev(L);
     const size_t ld = (size_t)3 * HD;
     const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
-    const int q = sb * 64 + wave * 16 + c;
+    const int q = sb * TROWS + wave * 16 + c;
+    const bool live = sb * TROWS + wave * 16 < L;  // this wave holds a real query (uniform per wave)
     const vec8 q0 = A::grow(base, ld, q, L, 0, lane), q1 = A::grow(base, ld, q, L, 1, lane);
     float m = -INFINITY, l = 0.f;
     f32x4 O[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nst = CAUSAL ? (sb + 1 < (L + 63) / 64 ? sb + 1 : (L + 63) / 64) : (L + 63) / 64;
+    const int nall = (L + 63) / 64, last_q = sb * TROWS + TROWS - 1;
+    const int nst = CAUSAL ? (last_q / 64 + 1 < nall ? last_q / 64 + 1 : nall) : nall;
+    Stage64<T> sg;
+    sg.load(base + HD, ld, base + 2 * HD, ld, 0, L, tid);
+    sg.write(Ks[0], Vs[0], tid);
+    __syncthreads();
     for (int st = 0; st < nst; ++st) {
-        __syncthreads();  // everyone is done with the previous stage's images
-        stage64<T>(Ks, base + HD, ld, Vs, base + 2 * HD, ld, st * 64, L, tid);
-        __syncthreads();
-        f32x4 S[4];
-        float mloc = -INFINITY;
+        const int cur = st & 1;
+        if (st + 1 < nst) sg.load(base + HD, ld, base + 2 * HD, ld, (st + 1) * 64, L, tid);
+        if (live && (!CAUSAL || st * 64 <= sb * TROWS + wave * 16 + 15)) {
+            f32x4 S[4];
+            float mloc = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            S[kt] = T::mfma16(A::rows(Ks, kt * 16, 0, lane), q0, S[kt]);
-            S[kt] = T::mfma16(A::rows(Ks, kt * 16, 1, lane), q1, S[kt]);
+            for (int kt = 0; kt < 4; ++kt) {
+                S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                S[kt] = T::mfma16(A::rows(Ks[cur], kt * 16, 0, lane), q0, S[kt]);
+                S[kt] = T::mfma16(A::rows(Ks[cur], kt * 16, 1, lane), q1, S[kt]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = st * 64 + kt * 16 + 4 * g + r;
-                if (key >= L || (CAUSAL && key > q)) S[kt][r] = -INFINITY;
-                mloc = fmaxf(mloc, S[kt][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = st * 64 + kt * 16 + 4 * g + r;
+                    if (key >= L || (CAUSAL && key > q)) S[kt][r] = -INFINITY;
+                    mloc = fmaxf(mloc, S[kt][r]);
+                }
+            }
+            const float mnew = fmaxf(m, group_max(mloc));  // finite from the first stage on: key 0 is visible to every query
+            const float alpha = mnew == -INFINITY ? 1.f : __builtin_amdgcn_exp2f((m - mnew) * SC), nm = mnew == -INFINITY ? 0.f : -mnew * SC;
+            m = mnew;
+            l *= alpha;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][r], SC, nm));
+                    S[kt][r] = e;
+                    l += e;
+                }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) O[dt] *= alpha;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const vec8 pb = A::pack2(S[2 * kc], S[2 * kc + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) O[dt] = T::mfma16(A::cols(Vs[cur], kc * 32, dt * 16, lane), pb, O[dt]);
             }
         }
-        const float mnew = fmaxf(m, group_max(mloc));  // finite from the first stage on: key 0 is visible to every query
-        const float alpha = mnew == -INFINITY ? 1.f : __builtin_amdgcn_exp2f((m - mnew) * SC), nm = mnew == -INFINITY ? 0.f : -mnew * SC;
-        m = mnew;
-        l *= alpha;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][r], SC, nm));
-                S[kt][r] = e;
-                l += e;
-            }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) O[dt] *= alpha;
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            const vec8 pb = A::pack2(S[2 * kc], S[2 * kc + 1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) O[dt] = T::mfma16(A::cols(Vs, kc * 32, dt * 16, lane), pb, O[dt]);
-        }
+        if (st + 1 < nst) sg.write(Ks[cur ^ 1], Vs[cur ^ 1], tid);
+        __syncthreads();  // stage st + 1 is in place; everyone is done reading stage st
     }
     l = group_sum(l);
     const size_t ldo = p.ld_out ? (size_t)p.ld_out : (size_t)HD;
@@ -989,12 +1004,12 @@ __global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(AttnArgs p, int nsb
 }
 
 template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(AttnArgs p, const void* fwd_out, int nsb) {
+__global__ __launch_bounds__(TW * 64) void attn_bwd_dq_tiled_kernel(AttnArgs p, const void* fwd_out, int nsb) {
     using A = Attn<T>;
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
-    __shared__ __attribute__((aligned(16))) elem Ks[64 * RS];
-    __shared__ __attribute__((aligned(16))) elem Vs[64 * RS];
+    __shared__ __attribute__((aligned(16))) elem Ks[2][64 * RS];
+    __shared__ __attribute__((aligned(16))) elem Vs[2][64 * RS];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = blockIdx.x / nsb, sb = blockIdx.x - pair * nsb, b = pair / p.H, hd = pair - b * p.H;
@@ -1003,8 +1018,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(AttnArgs p, cons
     const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
     const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
     const elem* Of = (const elem*)fwd_out + (size_t)b * L * ldof + hd * 64;
-    const int q = sb * 64 + wave * 16 + c;
-    if (p.sel_rows && ((p.sel_rows[b] - b * L) >> 6) != sb) {  // dO = 0 on this workgroup's 64 queries (uniform branch)
+    const int q = sb * TROWS + wave * 16 + c;
+    if (p.sel_rows && (p.sel_rows[b] - b * L) / TROWS != sb) {  // dO = 0 on this workgroup's queries (uniform branch)
         if (g == 0 && q < Lp) p.delta[(size_t)pair * Lp + q] = 0.f;
         const f32x4 z[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (q < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + q) * ld + hd * 64, z, 0.f, lane);
@@ -1019,53 +1034,62 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(AttnArgs p, cons
     delta = group_sum(delta);
     const size_t stat = (size_t)pair * Lp + (q < Lp ? q : 0);
     if (g == 0 && q < Lp) p.delta[stat] = delta;
-    // window form (uniform per wave): delta of every query, dQ only for the 16-row blocks that hold a wanted row; a wave that leaves
-    // skips the barriers below, so the decision is made per WORKGROUP (its 64 queries)
-    if (p.win_n > 0 && (sb * 64 >= p.win_row0 + p.win_n || sb * 64 + 64 <= p.win_row0)) return;
+    // window form: delta of every query, dQ only for the workgroups that hold a wanted row; a wave that leaves skips the barriers
+    // below, so the decision is made per WORKGROUP (its TROWS queries)
+    if (p.win_n > 0 && (sb * TROWS >= p.win_row0 + p.win_n || sb * TROWS + TROWS <= p.win_row0)) return;
+    const bool live = sb * TROWS + wave * 16 < L;
     const float nlse = q < L ? -p.lse[stat] * LOG2E : 0.f;
     f32x4 dQ[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nst = CAUSAL ? (sb + 1 < (L + 63) / 64 ? sb + 1 : (L + 63) / 64) : (L + 63) / 64;
+    const int nall = (L + 63) / 64, last_q = sb * TROWS + TROWS - 1;
+    const int nst = CAUSAL ? (last_q / 64 + 1 < nall ? last_q / 64 + 1 : nall) : nall;
+    Stage64<T> sg;
+    sg.load(base + HD, ld, base + 2 * HD, ld, 0, L, tid);
+    sg.write(Ks[0], Vs[0], tid);
+    __syncthreads();
     for (int st = 0; st < nst; ++st) {
-        __syncthreads();
-        stage64<T>(Ks, base + HD, ld, Vs, base + 2 * HD, ld, st * 64, L, tid);
-        __syncthreads();
+        const int cur = st & 1;
+        if (st + 1 < nst) sg.load(base + HD, ld, base + 2 * HD, ld, (st + 1) * 64, L, tid);
+        if (live && (!CAUSAL || st * 64 <= sb * TROWS + wave * 16 + 15)) {
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            f32x4 ds[2];
+            for (int kc = 0; kc < 2; ++kc) {
+                f32x4 ds[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int kt = 2 * kc + t;
-                f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {-delta, -delta, -delta, -delta};
-                S = T::mfma16(A::rows(Ks, kt * 16, 0, lane), q0, S);
-                S = T::mfma16(A::rows(Ks, kt * 16, 1, lane), q1, S);
-                dP = T::mfma16(A::rows(Vs, kt * 16, 0, lane), g0, dP);
-                dP = T::mfma16(A::rows(Vs, kt * 16, 1, lane), g1, dP);
+                for (int t = 0; t < 2; ++t) {
+                    const int kt = 2 * kc + t;
+                    f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {-delta, -delta, -delta, -delta};
+                    S = T::mfma16(A::rows(Ks[cur], kt * 16, 0, lane), q0, S);
+                    S = T::mfma16(A::rows(Ks[cur], kt * 16, 1, lane), q1, S);
+                    dP = T::mfma16(A::rows(Vs[cur], kt * 16, 0, lane), g0, dP);
+                    dP = T::mfma16(A::rows(Vs[cur], kt * 16, 1, lane), g1, dP);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = st * 64 + kt * 16 + 4 * g + r;
-                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nlse));
-                    if (key >= L || (CAUSAL && key > q)) pr = 0.f;
-                    ds[t][r] = pr * dP[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = st * 64 + kt * 16 + 4 * g + r;
+                        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nlse));
+                        if (key >= L || (CAUSAL && key > q)) pr = 0.f;
+                        ds[t][r] = pr * dP[r];
+                    }
                 }
-            }
-            const vec8 db = A::pack2(ds[0], ds[1]);
+                const vec8 db = A::pack2(ds[0], ds[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dQ[dt] = T::mfma16(A::cols(Ks, kc * 32, dt * 16, lane), db, dQ[dt]);
+                for (int dt = 0; dt < 4; ++dt) dQ[dt] = T::mfma16(A::cols(Ks[cur], kc * 32, dt * 16, lane), db, dQ[dt]);
+            }
         }
+        if (st + 1 < nst) sg.write(Ks[cur ^ 1], Vs[cur ^ 1], tid);
+        __syncthreads();
     }
     if (q < L) A::store_t((elem*)p.dqkv + ((size_t)b * L + q) * ld + hd * 64, dQ, 0.125f, lane);
 }
 
 template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_tiled_kernel(AttnArgs p, int nsb) {
+__global__ __launch_bounds__(TW * 64) void attn_bwd_dkv_tiled_kernel(AttnArgs p, int nsb) {
     using A = Attn<T>;
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
-    __shared__ __attribute__((aligned(16))) elem Qs[64 * RS];
-    __shared__ __attribute__((aligned(16))) elem Gs[64 * RS];
-    __shared__ float lse_s[64], del_s[64];
+    __shared__ __attribute__((aligned(16))) elem Qs[2][64 * RS];
+    __shared__ __attribute__((aligned(16))) elem Gs[2][64 * RS];
+    __shared__ float lse_s[2][64], del_s[2][64];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = blockIdx.x / nsb, sb = blockIdx.x - pair * nsb, b = pair / p.H, hd = pair - b * p.H;
@@ -1073,53 +1097,71 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_tiled_kernel(AttnArgs p, int
     const size_t ld = (size_t)3 * HD;
     const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
     const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
-    const int key = sb * 64 + wave * 16 + c;
-    if (p.win_n > 0 && (sb * 64 >= p.win_row0 + p.win_n || sb * 64 + 64 <= p.win_row0)) return;  // window form: no wanted key in this workgroup's 64
+    const int key = sb * TROWS + wave * 16 + c;
+    if (p.win_n > 0 && (sb * TROWS >= p.win_row0 + p.win_n || sb * TROWS + TROWS <= p.win_row0)) return;  // window form: no wanted key in this workgroup
+    const bool live = sb * TROWS + wave * 16 < L;
     const vec8 k0 = A::grow(base + HD, ld, key, L, 0, lane), k1 = A::grow(base + HD, ld, key, L, 1, lane);
     const vec8 v0 = A::grow(base + 2 * HD, ld, key, L, 0, lane), v1 = A::grow(base + 2 * HD, ld, key, L, 1, lane);
     f32x4 dK[4], dV[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const int st_sel = p.sel_rows ? (p.sel_rows[b] - b * L) >> 6 : -1;  // dO is zero outside this 64-query stage
-    const int st_lo = CAUSAL ? sb : 0;  // causal: query stages that hold a query >= this workgroup's first key
+    const int st_lo = CAUSAL ? (sb * TROWS) >> 6 : 0;  // causal: query stages that hold a query >= this workgroup's first key
     const int st0 = st_sel >= 0 ? (st_sel > st_lo ? st_sel : st_lo) : st_lo, nst = st_sel >= 0 ? st_sel + 1 : (L + 63) / 64;
-    for (int st = st0; st < nst; ++st) {
-        __syncthreads();
-        stage64<T>(Qs, base, ld, Gs, dO, (size_t)HD, st * 64, L, tid);
+    Stage64<T> sg;
+    float lse_v = 0.f, del_v = 0.f;
+    auto load_stats = [&](int st) {
         if (tid < 64) {
             const int qi = st * 64 + tid;
-            lse_s[tid] = qi < L ? -p.lse[(size_t)pair * Lp + qi] * LOG2E : -INFINITY;  // padding queries: p = 0
-            del_s[tid] = qi < L ? p.delta[(size_t)pair * Lp + qi] : 0.f;
+            lse_v = qi < L ? -p.lse[(size_t)pair * Lp + qi] * LOG2E : -INFINITY;  // padding queries: p = 0
+            del_v = qi < L ? p.delta[(size_t)pair * Lp + qi] : 0.f;
         }
-        __syncthreads();
+    };
+    if (st0 < nst) {
+        sg.load(base, ld, dO, (size_t)HD, st0 * 64, L, tid);
+        load_stats(st0);
+        sg.write(Qs[0], Gs[0], tid);
+        if (tid < 64) { lse_s[0][tid] = lse_v; del_s[0][tid] = del_v; }
+    }
+    __syncthreads();
+    for (int st = st0; st < nst; ++st) {
+        const int cur = (st - st0) & 1;
+        if (st + 1 < nst) { sg.load(base, ld, dO, (size_t)HD, (st + 1) * 64, L, tid); load_stats(st + 1); }
+        if (live && (!CAUSAL || st * 64 + 63 >= sb * TROWS + wave * 16)) {
 #pragma unroll
-        for (int qc = 0; qc < 2; ++qc) {
-            f32x4 P[2], dS[2];
+            for (int qc = 0; qc < 2; ++qc) {
+                f32x4 P[2], dS[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int qt = 2 * qc + t;
-                const f32x4 nl = *(const f32x4*)(lse_s + qt * 16 + 4 * g);
-                const f32x4 d4 = *(const f32x4*)(del_s + qt * 16 + 4 * g);
-                f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = -d4;
-                S = T::mfma16(A::rows(Qs, qt * 16, 0, lane), k0, S);
-                S = T::mfma16(A::rows(Qs, qt * 16, 1, lane), k1, S);
-                dP = T::mfma16(A::rows(Gs, qt * 16, 0, lane), v0, dP);
-                dP = T::mfma16(A::rows(Gs, qt * 16, 1, lane), v1, dP);
+                for (int t = 0; t < 2; ++t) {
+                    const int qt = 2 * qc + t;
+                    const f32x4 nl = *(const f32x4*)(lse_s[cur] + qt * 16 + 4 * g);
+                    const f32x4 d4 = *(const f32x4*)(del_s[cur] + qt * 16 + 4 * g);
+                    f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = -d4;
+                    S = T::mfma16(A::rows(Qs[cur], qt * 16, 0, lane), k0, S);
+                    S = T::mfma16(A::rows(Qs[cur], qt * 16, 1, lane), k1, S);
+                    dP = T::mfma16(A::rows(Gs[cur], qt * 16, 0, lane), v0, dP);
+                    dP = T::mfma16(A::rows(Gs[cur], qt * 16, 1, lane), v1, dP);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nl[r]));
-                    if (CAUSAL && key > st * 64 + qt * 16 + 4 * g + r) pr = 0.f;
-                    P[t][r] = pr;
-                    dS[t][r] = pr * dP[r];
+                    for (int r = 0; r < 4; ++r) {
+                        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], SC, nl[r]));
+                        if (CAUSAL && key > st * 64 + qt * 16 + 4 * g + r) pr = 0.f;
+                        P[t][r] = pr;
+                        dS[t][r] = pr * dP[r];
+                    }
+                }
+                const vec8 pb = A::pack2(P[0], P[1]), db = A::pack2(dS[0], dS[1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dV[dt] = T::mfma16(A::cols(Gs[cur], qc * 32, dt * 16, lane), pb, dV[dt]);
+                    dK[dt] = T::mfma16(A::cols(Qs[cur], qc * 32, dt * 16, lane), db, dK[dt]);
                 }
             }
-            const vec8 pb = A::pack2(P[0], P[1]), db = A::pack2(dS[0], dS[1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                dV[dt] = T::mfma16(A::cols(Gs, qc * 32, dt * 16, lane), pb, dV[dt]);
-                dK[dt] = T::mfma16(A::cols(Qs, qc * 32, dt * 16, lane), db, dK[dt]);
-            }
         }
+        if (st + 1 < nst) {
+            sg.write(Qs[cur ^ 1], Gs[cur ^ 1], tid);
+            if (tid < 64) { lse_s[cur ^ 1][tid] = lse_v; del_s[cur ^ 1][tid] = del_v; }
+        }
+        __syncthreads();
     }
     if (key < L) {
         elem* ok = (elem*)p.dqkv + ((size_t)b * L + key) * ld + HD + hd * 64;
@@ -1131,10 +1173,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_tiled_kernel(AttnArgs p, int
 template <typename T, bool BWD>
 static int tiled_launch(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
     const LaunchProf p1{prof ? prof->start : nullptr, nullptr}, p2{nullptr, prof ? prof->stop : nullptr};
-    const int nsb = (a.L + 63) / 64;
+    const int nsb = (a.L + TROWS - 1) / TROWS;
     const size_t nwg = (size_t)a.B * a.H * nsb;
     ARG_CHECK(nwg < 0x7fffffffull, "attention: too many workgroups (%zu)", nwg);
-    const dim3 grid((unsigned)nwg), block(256);
+    const dim3 grid((unsigned)nwg), block(TW * 64);
     if (!BWD) {
         if (a.causal) MUDPT_LAUNCH((attn_fwd_tiled_kernel<T, true>), grid, block, 0, s, prof, a, nsb);
         else MUDPT_LAUNCH((attn_fwd_tiled_kernel<T, false>), grid, block, 0, s, prof, a, nsb);

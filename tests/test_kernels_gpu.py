@@ -490,7 +490,7 @@ def test_attention_single_query(lib, dtype, B, L, H, causal):
 @pytest.mark.parametrize("B,L,H,causal,row0,n", [(3, 201, 12, False, 197, 4), (2, 77, 8, True, 1, 4), (3, 150, 2, False, 14, 4), (2, 581, 4, False, 577, 4),
                                                  (2, 581, 2, False, 62, 5), (4, 26, 8, True, 1, 16)])
 def test_attention_backward_window_form(lib, B, L, H, causal, row0, n):
-    """Block 0 of a tower needs d(qkv) on the prompt rows only: the window form computes the 16-row blocks (L > 224: 64-row groups) that hold
+    """Block 0 of a tower needs d(qkv) on the prompt rows only: the window form computes the 16-row blocks (L > 224: 128-row groups) that hold
     rows row0 .. row0 + n - 1 of every sequence -- dQ from all keys, dK / dV from all queries -- and leaves the other rows unwritten.  The
     wanted rows equal the two-kernel form's bit for bit (same sums, same order); the rest of the buffer keeps its previous contents outside
     the computed blocks."""
@@ -511,7 +511,7 @@ def test_attention_backward_window_form(lib, B, L, H, causal, row0, n):
     torch.cuda.synchronize()
     assert torch.equal(win[:, row0:row0 + n], full[:, row0:row0 + n])
     assert torch.equal(delta[..., :L], delta_full[..., :L])  # delta of every query feeds the dK / dV pass
-    gran = 64 if L > 224 else 16
+    gran = 128 if L > 224 else 16
     lo, hi = row0 // gran * gran, min(L, -(-(row0 + n) // gran) * gran)
     untouched = torch.ones(L, dtype=torch.bool)
     untouched[lo:hi] = False

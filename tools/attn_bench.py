@@ -11,6 +11,29 @@ from mudpt_amd import capi
 def main():
     lib = capi.load()
     P = lambda t: C.c_void_p(t.data_ptr())
+    if "--long" in sys.argv:  # BASELINE configs[4]: ViT-L/14@336, B 128, L 581, H 16 (the tiled kernels)
+        B, L, H = 128, 581, 16
+        Lp = lib.mudpt_attention_padded_len(L)
+        qkv = torch.randn(B, L, 3 * H * 64, device="cuda").to(torch.bfloat16)
+        dout = torch.randn(B, L, H * 64, device="cuda").to(torch.bfloat16)
+        out = torch.empty(B, L, H * 64, device="cuda", dtype=torch.bfloat16)
+        dqkv, lse, delta = torch.empty_like(qkv), torch.zeros(B, H, Lp, device="cuda"), torch.zeros(B, H, Lp, device="cuda")
+        fl = 4.0 * B * H * L * L * 64
+        for nm, fn, mult in (("fwd", lambda: lib.mudpt_attention_fwd(0, P(qkv), P(out), P(lse), B, L, H, 0, None), 1.0),
+                             ("bwd (dQ kernel + dK/dV kernel)", lambda: lib.mudpt_attention_bwd(0, P(qkv), P(out), P(dout), P(lse), P(delta), P(dqkv), B, L, H, 0, None), 3.5)):
+            assert fn() == 0
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 5)
+            print(f"ViT-L/14@336 B {B} L {L} H {H} {nm}: {best * 1e3:7.1f} us ({mult * fl / best / 1e9:6.1f} TF/s executed)", flush=True)
+        return
     for name, B, L, H, causal in (("vision", 256, 201, 12, 0), ("vision, head-contiguous (B*H seqs, H=1)", 3072, 201, 1, 0), ("text", 11, 77, 8, 1), ("text1000", 1000, 77, 8, 1)):
         Lp = lib.mudpt_attention_padded_len(L)
         qkv = torch.randn(B, L, 3 * H * 64, device="cuda").to(torch.bfloat16)
