@@ -69,7 +69,15 @@ def cpu_baseline(n_cls: int = 11, iters: int = 12):
 
 
 PEAK_HBM_GBS = 8000.0  # HBM3E spec (MI355X_MICROARCH.md; ~6300 GB/s achievable by a streaming copy)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_bytes_per_step.json")  # tools/prof_join.py output of the same command (PMC passes)
+# tools/prof_join.py output of the same command under rocprofv3 (separate --pmc FETCH_SIZE / WRITE_SIZE passes; tools/profile_round.sh),
+# committed per workload: (arch, batch, classes, dtype) -> profiles/<tag>_bytes_per_step.json
+TRAFFIC_TAGS = {("vit_b16", 256, 11, "bf16"): "r03", ("vit_b16", 256, 11, "fp16"): "r03_fp16", ("vit_b16", 256, 11, "fp32"): "r03_fp32",
+                ("vit_b16", 256, 1000, "bf16"): "r03_c1000", ("vit_l14_336", 128, 1000, "bf16"): "r03_vitl"}
+
+
+def traffic_json(arch, B, C, dtype):
+    tag = TRAFFIC_TAGS.get((arch, B, C, dtype))
+    return os.path.join(ROOT, "profiles", f"{tag}_bytes_per_step.json") if tag else None
 
 
 def launch_ranks(n: int) -> int:
@@ -337,7 +345,8 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}" + ("+class-parallel text tower" if args.class_parallel and world > 1 else ""), "final_loss": round(loss_v, 4),
                        "step_tflop": round(step_flop / 1e12, 3)},
         }
-        traffic_db = json.load(open(TRAFFIC_JSON)).get("classes", {}) if os.path.exists(TRAFFIC_JSON) and B == 256 and C == 11 and args.dtype == "bf16" and args.arch == "vit_b16" else {}
+        tj = traffic_json(args.arch, B, C, args.dtype)
+        traffic_db = json.load(open(tj)).get("classes", {}) if tj and os.path.exists(tj) else {}
         if gemm_n:
             ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
             # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (PMC counters cannot be read from
@@ -355,7 +364,7 @@ def main():
                             "traffic": round(traffic_db[cls]["traffic_bytes_per_launch"]) if cls in traffic_db else None}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": round(pmc["traffic_bytes_per_launch"]) if pmc else None,
-                               "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE of separate --pmc passes, profiles/r02_bytes_per_step.md)",
+                               "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE of separate --pmc passes: " + (os.path.relpath(tj, ROOT).replace(".json", ".md") if traffic_db else "no tracked profile for this workload") + ")",
                                "flop_per_launch": round(gemm_flop / gemm_n),
                                "kernel": f"gemm_pp_kernel (persistent MFMA GEMM: the {round(gemm_n * stride / args.steps)} big vision-tower GEMM launches per step; "
                                          f"achieved = executed 2MNK / HIP-event time of the bracketed launches: every {stride}-th launch, counted across "

@@ -153,25 +153,35 @@ int mudpt_sgd_step(mudpt_model* m, float lr, float momentum, float weight_decay,
                    int32_t nesterov, void* stream);
 int mudpt_sgd_reset(mudpt_model* m);
 
+/* ======================================================================================================================================
+ * Everything below this line is TEST / MEASUREMENT / DEBUG surface, not part of the drop-in boundary: a trainer plugin needs none of it.
+ * ====================================================================================================================================== */
+
 /* Test hook: copy an internal fp32 activation of the last call to HOST memory (synchronises the device).
  * name: "vis.x_in.<i>" / "txt.x_in.<i>" (input of block i, after the prompt splice; [seq, L, d], text L = max(eot) + 1), "vis.x_out" / "txt.x_out"
  * (output of the last block on the ONE row per sequence the model uses -- CLS / EOT token -- [seq, d]: the tail of the last
  * block runs on those rows only), "image_features", "text_features".  host_out may be NULL to query *numel. */
 int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* host_out, size_t capacity, size_t* numel);
 
-/* Per-handle tuning knobs for A/B measurements in one process (tools/gemm_bench.py, tests); nothing is process-global, so two
- * models in one process do not interfere: "gemm_variant"; "attn_window" (0 = block 0's attention backward on all rows instead of the prompt rows' blocks);
- * "split_k" (0 = never split the contraction of the small-grid, long-K GEMMs);
- * "last_single" (0 = the last block's attention on all rows instead of the
- * single-query form); "attn_two_kernels" (1 = attention backward as two kernels); "cocoop_chunk"
- * (cap on the images per CoCoOp text-tower pass; read by the next mudpt_set_class_prompts); "lp_grad" (gradient stream of the residual in T: default in bf16 mode, where 0 also returns the forward's update stream to fp32;
- * 1 in fp16 mode trades 30 % more gradient error for 0.9 ms);
- * "lp_upd" (the forward's update stream in T: default in bf16 mode, off in fp16 mode where it would cost 2e-4 of logit error);
- * "txt_buckets" (maximum number of length buckets
- * of the class prompts, 1 = none) and "txt_bucket_cost" (token rows one more bucket must save, default 1024; both read by the next
- * mudpt_set_class_prompts); "prof_stride" (measurement mode brackets every prof_stride-th persistent-GEMM launch, counted across steps);
- * "txt_split" (fp16 mode: 0 = no split operands in the text tower; only before the first mudpt_set_weight); "txt_trim"
- * (0 = run the text tower on all ctx_len positions; read by the next mudpt_set_class_prompts, which must follow). */
+/* Debug knobs of ONE handle, for A/B measurements in one process and for tests (tools/gemm_bench.py, bench.py flags, tests/).  Nothing is
+ * process-global: two models in one process do not interfere.  Defaults are what the product runs; no knob is needed for correct results.
+ *
+ *   knob               default         meaning
+ *   gemm_variant       0               kernel choice of the MFMA GEMMs (gemm.hip launch_epi / gemm_pp.hip; 0 = the default dispatch)
+ *   split_k            1               0 = never split the contraction of the small-grid, long-K backward GEMMs
+ *   attn_window        1               0 = block 0's attention backward on all rows instead of the prompt rows' blocks
+ *   last_single        1 (0 exact)     0 = the last block's attention on all rows instead of the single-query form
+ *   attn_two_kernels   0               1 = attention backward as the dQ + dK/dV kernel pair
+ *   attn_fused_w1      0               1 = fused attention backward with two 16-row blocks per wave
+ *   lp_grad            bf16: 1, else 0 gradient stream of the residual in T (bf16 mode: 0 also returns the forward's update stream to fp32;
+ *                                      fp16 mode: 1 trades 30 % more gradient error for 0.9 ms)
+ *   lp_upd             bf16: 1, else 0 the forward's update stream in T (fp16 mode: would cost 2e-4 of logit error)
+ *   txt_split          fp16 / fp32: 1  0 = no split operands in the text tower (fp16 mode; only before the first mudpt_set_weight)
+ *   txt_trim           1               0 = run the text tower on all ctx_len positions        } read by the next
+ *   txt_buckets        3               maximum number of length buckets of the class prompts  } mudpt_set_class_prompts,
+ *   txt_bucket_cost    1024            token rows one more bucket must save                   } which must follow
+ *   cocoop_chunk       0 (= budget)    cap on the images per CoCoOp text-tower pass           }
+ *   prof_stride        1               measurement mode brackets every prof_stride-th persistent-GEMM launch, counted across steps */
 int mudpt_model_set(mudpt_model* m, const char* name, int32_t value);
 
 /* Measurement hook (bench.py): bracket every MFMA GEMM launch of the path with HIP events on its launch stream.

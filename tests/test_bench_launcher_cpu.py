@@ -49,3 +49,16 @@ def test_a_failing_rank_ends_the_job():
     env.update(MUDPT_BENCH_STUB="1", MUDPT_BENCH_STUB_FAIL_RANK="1")
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+
+
+def test_every_tracked_workload_has_its_traffic_profile():
+    """bench.py's roofline.traffic comes from the rocprofv3 PMC passes committed under profiles/ for the SAME workload (tools/profile_round.sh);
+    every workload it knows a tag for must have its file, with the dominant kernel's class in it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for key, tag in bench.TRAFFIC_TAGS.items():
+        path = bench.traffic_json(*key)
+        assert path and os.path.exists(path), (key, tag)
+        classes = json.load(open(path))["classes"]
+        assert classes["gemm_pp"]["traffic_bytes_per_launch"] > 0, tag
+    assert bench.traffic_json("vit_b16", 4, 50, "bf16") is None  # no tracked profile: traffic is reported as null

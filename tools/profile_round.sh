@@ -15,7 +15,7 @@ rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o w --output-format csv -- python3 "
 T=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1); F=$(find "$OUT/fetch" -name "*counter_collection.csv" | head -1); W=$(find "$OUT/write" -name "*counter_collection.csv" | head -1)
 python3 "$ROOT/tools/prof_join.py" --trace "$T" --fetch "$F" --write "$W" --steps $((TS + TW + HB)) --pmc-steps $((PS + PW)) \
     --title "HBM-side bytes per kernel joined with the kernel trace ($TAG)" \
-    --note "Command: \`python3 bench.py --steps $TS --warmup $TW --no-cpu-baseline --no-parity-mode $*\` under \`rocprofv3 --kernel-trace --stats\` (\$((TS + TW + HB)) steps in the trace: warm-up, timed, and the \$HB steps of the HBM-kernel pass); PMC passes: the same with \`--steps $PS --warmup $PW --no-profile\` under \`--pmc FETCH_SIZE\` / \`--pmc WRITE_SIZE\`." \
+    --note "Command: \`python3 bench.py --steps $TS --warmup $TW --no-cpu-baseline --no-parity-mode $*\` under \`rocprofv3 --kernel-trace --stats\` ($((TS + TW + HB)) steps in the trace: warm-up, timed, and the $HB steps of the HBM-kernel pass); PMC passes: the same with \`--steps $PS --warmup $PW --no-profile\` under \`--pmc FETCH_SIZE\` / \`--pmc WRITE_SIZE\`." \
     --out-md "$OUT/bytes_per_step.md" --out-json "$OUT/bytes_per_step.json" > "$OUT/join.log" 2>&1 || { tail -5 "$OUT/join.log"; exit 1; }
 cp "$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats.csv"
 tail -1 "$OUT/trace.log"
