@@ -198,6 +198,8 @@ def main():
     if os.environ.get("MUDPT_BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo collectives
         local = 0
     torch.cuda.set_device(local)
+    if world > 1:  # N ranks build their (seeded, CPU-side) synthetic weights at the same time: share the host cores instead of oversubscribing them N-fold
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -10,7 +10,7 @@
 //   out: out [B, L, ld_out] fp16 = hi(O) and out_lo = fp16(O - hi): the split operand of the out_proj GEMM; lse [B, H, Lp];
 //        qkv_lp [B, L, 3 H 64] fp16: the copy the (fp16-operand) backward kernels read
 //
-// One workgroup = 4 waves = 64 queries of one (sequence, head); a wave owns 16 queries.  Keys / values stream through LDS in tiles of
+// One workgroup = 8 waves = 128 queries of one (sequence, head); a wave owns 16 queries.  Keys / values stream through LDS in tiles of
 // 32 keys (fp32 rows of 256 bytes, double buffered, staged through registers).  Operand maps of the 16x16x4 f32 MFMA: lane l holds
 // A[l & 15][l >> 4], B[l >> 4][l & 15], D[4 (l >> 4) + r][l & 15].  With n = l & 15, g = l >> 4:
 //   S^T[key][query] = K . Q^T : A = K[key n][d = 16 g + s], B = Q[query n][d = 16 g + s], s = 0..15 (any partition of d over the
@@ -26,13 +26,14 @@ namespace mudpt {
 namespace {
 
 constexpr int XKT = 32;  // keys per staged tile
+constexpr int XW = 8, XQ = XW * 16;  // waves / queries per workgroup (round 3: 4 / 64 read K and V of a pair four times over: 1.4 GB per ViT-B/16 layer at B 256)
 
 // slot swizzle of the K image: within a ds_read_b128 lane group {n in 0-3, 12-15 with k-slot g} + {n in 4-11 with k-slot g ^ 1}
 // the slots (4 g + j) ^ kswz(n) are 16 distinct chunks of the 256-byte bank row
 __device__ inline int kswz(int n) { return n ^ ((((n >> 2) ^ (n >> 3)) & 1) << 2); }
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_exact_kernel(AttnArgs p, int nchunks) {
+__global__ __launch_bounds__(XW * 64) void attn_fwd_exact_kernel(AttnArgs p, int nchunks) {
     __shared__ __attribute__((aligned(16))) float sm[2][2][XKT * 64];  // [buffer][K | V][key][64]: 32 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void attn_fwd_exact_kernel(AttnArgs p, int nch
     _Float16* lp = (_Float16*)p.qkv_lp;
     if (lp) lp += (size_t)b * L * ld + h * 64;
 
-    const int q0 = qc * 64 + w * 16, qrow = q0 + n;
+    const int q0 = qc * XQ + w * 16, qrow = q0 + n;
     const bool qvalid = qrow < L;
     // Q fragment: Q[qrow][16 g + s]
     float qf[16];
@@ -67,16 +68,18 @@ __global__ __launch_bounds__(256) void attn_fwd_exact_kernel(AttnArgs p, int nch
     }
 
     // keys this workgroup needs: all (non-causal) / up to its last query (causal)
-    const int klast = CAUSAL ? (qc * 64 + 63 < L - 1 ? qc * 64 + 63 : L - 1) : L - 1;
+    const int klast = CAUSAL ? (qc * XQ + XQ - 1 < L - 1 ? qc * XQ + XQ - 1 : L - 1) : L - 1;
     const int nt = klast / XKT + 1;
     const bool copy_kv = lp && qc == nchunks - 1;  // the last query chunk stages every key of the sequence: it writes the fp16 copies of k, v
 
-    // staging: thread -> 2 chunks of K and 2 of V per tile (chunk e = tid + 256 r: key e >> 4, 16-byte chunk e & 15)
-    f32x4 stg[2][2];
+    // staging: thread -> SR chunks of K and of V per tile (chunk e = tid + 64 XW r: key e >> 4, 16-byte chunk e & 15)
+    constexpr int SR = XKT * 16 / (XW * 64);
+    static_assert(SR >= 1 && SR * XW * 64 == XKT * 16, "a tile's 16-byte chunks must split evenly over the threads");
+    f32x4 stg[SR][2];
     auto stage_load = [&](int t) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int e = tid + 256 * r, key = t * XKT + (e >> 4), c = e & 15;
+        for (int r = 0; r < SR; ++r) {
+            const int e = tid + XW * 64 * r, key = t * XKT + (e >> 4), c = e & 15;
             const bool ok = key < L;
             const float* src = base + (size_t)(ok ? key : 0) * ld + 4 * c;
             stg[r][0] = ok ? *(const f32x4*)(src + HD) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(256) void attn_fwd_exact_kernel(AttnArgs p, int nch
     };
     auto stage_write = [&](int t, int buf) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int e = tid + 256 * r, kl = e >> 4, c = e & 15, key = t * XKT + kl;
+        for (int r = 0; r < SR; ++r) {
+            const int e = tid + XW * 64 * r, kl = e >> 4, c = e & 15, key = t * XKT + kl;
             *(f32x4*)&sm[buf][0][kl * 64 + ((c ^ kswz(kl & 15)) << 2)] = stg[r][0];
             *(f32x4*)&sm[buf][1][kl * 64 + (c << 2)] = stg[r][1];
             if (copy_kv && key < L) {
@@ -199,10 +202,10 @@ int launch_attn_fwd_exact(const AttnArgs& a, hipStream_t s, const LaunchProf* pr
     ARG_CHECK(ld_out % 8 == 0 && ((uintptr_t)a.out % 16 == 0) && ((uintptr_t)a.out_lo % 16 == 0) && ((uintptr_t)a.qkv32 % 16 == 0) && ((uintptr_t)a.qkv_lp % 16 == 0),
               "attention (exact): operands must be 16-byte aligned");
     ARG_CHECK((size_t)a.B * a.H < 0x7fffffffull, "attention (exact): too many (sequence, head) pairs");
-    const int nchunks = (a.L + 63) / 64;
+    const int nchunks = (a.L + XQ - 1) / XQ;
     const dim3 grid((unsigned)(a.B * a.H), (unsigned)nchunks);
-    if (a.causal) MUDPT_LAUNCH(attn_fwd_exact_kernel<true>, grid, dim3(256), 0, s, prof, a, nchunks);
-    else MUDPT_LAUNCH(attn_fwd_exact_kernel<false>, grid, dim3(256), 0, s, prof, a, nchunks);
+    if (a.causal) MUDPT_LAUNCH(attn_fwd_exact_kernel<true>, grid, dim3(XW * 64), 0, s, prof, a, nchunks);
+    else MUDPT_LAUNCH(attn_fwd_exact_kernel<false>, grid, dim3(XW * 64), 0, s, prof, a, nchunks);
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;
 }

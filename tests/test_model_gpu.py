@@ -21,8 +21,8 @@ TINY_SLACK = 1.5
 GRAD_RTOL = {"fp16": 2e-2, "bf16": 1.5e-1}  # relative to each gradient tensor's RMS: single elements may be off by 4x this
 # RMS of the error over a whole gradient tensor, relative to the tensor's RMS (the error model of tests/test_cocoop_gpu.py without the
 # cancellation factor: MuDPT's gradients are sums of same-signed-on-average terms).  Measured on MI355X (round 3): fp16 <= 2.6e-3,
-# bf16 <= 2.4e-2 over the four fixtures; the bounds leave a factor ~2.
-GRAD_RMS = {"fp16": 6e-3, "bf16": 5e-2}
+# bf16 <= 3.8e-2 over the four fixtures; the bounds leave a factor 2.3 / 1.6.
+GRAD_RMS = {"fp16": 6e-3, "bf16": 6e-2}
 
 
 def build(case: GoldenCase, dtype: str, max_batch=None, knobs=None):
@@ -266,3 +266,29 @@ def test_training_trajectory_tracks_the_oracle(dtype):
     print(f"{dtype}: parameters moved {moved:.3e} rms, library - oracle {err:.3e} rms")
     assert err <= {"fp16": 2e-2, "bf16": 1.5e-1}[dtype] * moved
     m.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_split_k_backward_agrees_with_the_sequential_contraction(dtype):
+    """B = 4 ViT-B/16 (M = 804 rows): the backward's long-K store GEMMs (dfc K 3072, dqkv K 2304, the text tower's) split K over up to four
+    slices whose fp32 partials are summed in slice order (gemm.hip split_k_slices: whether and how a shape splits depends on M and on the
+    CU count, so gradients are bit-reproducible for a fixed shape and device only; the forward never splits).  Knob split_k = 0 contracts
+    sequentially: logits and loss are BIT-identical (the forward is untouched), gradients agree to the rounding of differently associated
+    fp32 sums, far inside the bound both hold against the reference."""
+    case = GoldenCase("mudpt_vitb16_b4")
+    out = {}
+    for sk in (1, 0):
+        m = build(case, dtype, knobs={"split_k": sk})
+        loss, logits = m.forward_backward(case.images, case.labels, return_logits=True)
+        torch.cuda.synchronize()
+        out[sk] = (logits.cpu(), loss.item(), {k: g.detach().cpu().clone() for k, g in m.grads().items()})
+        m.close()
+    assert torch.equal(out[1][0], out[0][0]) and out[1][1] == out[0][1]
+    differs = False
+    for k, g in out[0][2].items():
+        rms = g.pow(2).mean().sqrt().item()
+        d = (out[1][2][k] - g)
+        differs |= bool(d.abs().max().item() > 0)
+        assert d.pow(2).mean().sqrt().item() <= GRAD_RMS[dtype] * rms + 1e-12, k
+        assert d.abs().max().item() <= GRAD_RTOL[dtype] * rms * 4 + 1e-9, k
+    assert differs, "the shapes of this case are expected to split (M = 804: 84 workgroups of 128 x 64 on 256 CUs)"
