@@ -244,3 +244,19 @@ def test_full_size_cocoop_b64_properties_bf16():
     # meta_net's gradients are sums of nearly cancelling per-class terms (tests/test_cocoop_gpu.py): bf16 noise is amplified
     batch_properties(m, images, labels, 16, 0.35)
     m.close()
+
+
+def test_full_size_exact_mode_properties():
+    """BASELINE configs[1]'s size (ViT-B/16, B = 256, C = 11) in the EXACT mode (dtype "fp32"): the split-operand GEMMs at M = 51 456 (the
+    persistent kernel's fp32 and [hi | lo] epilogues), the fp32 attention forward over 3072 (sequence, head) pairs, the [hi | lo] patch
+    rows -- held to the same size-independent properties as the bf16 runs (chunk / permutation equality of the logits bit for bit, loss =
+    mean of chunk losses, batch gradient = mean of chunk gradients), with the fp16 backward's noise level."""
+    from mudpt_amd import synth
+    from mudpt_amd.model import CustomCLIP, ModelShape
+    shape = ModelShape()
+    m = CustomCLIP(shape, synth.random_clip_state(shape, seed=0), synth.bench_tokenized_prompts(), ctx_token_ids=synth.CTX_INIT_TOKENS,
+                   max_batch=256, dtype="fp32", seed=1)
+    g = torch.Generator().manual_seed(14)
+    images, labels = torch.randn(256, 3, 224, 224, generator=g).cuda(), torch.randint(0, 11, (256,), generator=g).cuda()
+    batch_properties(m, images, labels, 64, 0.02)
+    m.close()
