@@ -306,6 +306,12 @@ if __name__ == "__main__":
             taps_wanted=False, logit_scale=100.0)
         run_cocoop(O.TINY, "cocoop_tiny_s100", "a photo", batch=3, frozen_seed=21, train_seed=22, image_seed=23, logit_scale=100.0)
         run_cocoop(O.VIT_B16, "cocoop_vitb16_b2_s100", "a photo of a", batch=2, frozen_seed=0, train_seed=2, image_seed=4321, logit_scale=100.0)
+        # the two other shapes of work at that scale: 208 class prompts of mixed length (length buckets, per-class EOT rows) and ViT-L/14@336
+        # (depth 24, L = 581: the tiled attention kernels; embed 768)
+        run(O.VIT_B16, "mudpt_vitb16_c208_b2_s100", "a photo of a", batch=2, frozen_seed=0, train_seed=3, image_seed=2468,
+            sample_big=True, classnames=many_classnames(208), taps_wanted=False, logit_scale=100.0)
+        run(O.VIT_L14_336, "mudpt_vitl14_336_b1_s100", "a photo of a", batch=1, frozen_seed=5, train_seed=6, image_seed=77, sample_big=True,
+            taps_wanted=False, logit_scale=100.0)
         sys.exit(0)
     if "--many-only" in sys.argv:
         # BASELINE configs[2]'s shape of work at fixture size: ViT-B/16, 208 class prompts of mixed length (EOT 7..17), B = 2

@@ -61,7 +61,7 @@ def test_exact_attention_forward(B, L, H, causal):
     assert (hi[..., d:].float().abs().cpu() <= 0.5 * ulp * (1 + 1e-3)).all()
 
 
-@pytest.mark.parametrize("name", ["mudpt_tiny_s100", "mudpt_vitb16_b4_s100"])
+@pytest.mark.parametrize("name", ["mudpt_tiny_s100", "mudpt_vitb16_b4_s100", "mudpt_vitb16_c208_b2_s100", "mudpt_vitl14_336_b1_s100"])
 def test_logits_at_scale_100_within_1e_3(name):
     case = GoldenCase(name)
     assert abs(case.frozen["logit_scale"].exp().item() - 100.0) < 1e-3

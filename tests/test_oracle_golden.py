@@ -40,7 +40,7 @@ def test_many_class_fixture_matches_reference():
     test_forward_backward_matches_reference(c)
 
 
-@pytest.mark.parametrize("name", ["mudpt_tiny_s100", "mudpt_vitb16_b4_s100"])
+@pytest.mark.parametrize("name", ["mudpt_tiny_s100", "mudpt_vitb16_b4_s100", "mudpt_vitb16_c208_b2_s100", "mudpt_vitl14_336_b1_s100"])
 def test_scale100_fixture_matches_reference(name):
     """exp(logit_scale) = 100, what every released CLIP checkpoint holds (the reference multiplies the cosine by it, trainers/mudpt.py:181-182;
     init value 1/0.07 = 14.29, clip/model.py:777): the fixtures come from the reference's modules with that one parameter changed."""
@@ -53,7 +53,7 @@ def test_scale100_fixture_matches_reference(name):
     print(f"{name}: oracle vs reference logits max {err:.3e}")
     # fp32 on both sides: the summation-order noise of the cosine (~1e-6) times 100
     torch.testing.assert_close(logits, c.logits, atol=1.5e-4, rtol=1e-5)
-    assert abs(loss.item() - c.loss) < 2e-5
+    assert abs(loss.item() - c.loss) < (2e-5 if c.logits.shape[1] <= 11 else 1e-4)  # 208 classes: the loss sums the logits' fp32 noise over more terms
     for k in O.TRAINABLE_ORDER:
         g, s = grads[k], c.z["grad_sum." + k]
         scale = float(s[1]) / max(g.numel() ** 0.5, 1.0)
