@@ -111,6 +111,7 @@ struct AttnArgs {
     // dK / dV from all queries, same sums in the same order as without the window -- and every other row of dqkv is left UNWRITTEN.
     // Honoured by the two-kernel form (whole sequence on chip, non-causal) and the tiled kernels; elsewhere everything is computed.
     int win_row0 = 0, win_n = 0;
+    bool tiled_fwd_16 = false;  // fwd, 224 < L <= 640: the staged 16-query-block kernel instead of the resident form (A/B runs, tests)
     int B = 0, L = 0, H = 0; bool causal = false;
     // exact-fp32 forward (attention_exact.hip): q | k | v in fp32 [B, L, 3*H*64] and, optionally, where to leave their T copy for the backward
     const float* qkv32 = nullptr;

@@ -1716,7 +1716,8 @@ extern "C" int mudpt_attention_bwd_single(int32_t dtype, const void* qkv, const 
 }
 extern "C" int mudpt_attention_padded_len(int32_t L) { return attn_padded_len(L); }
 extern "C" int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H, int32_t causal, void* stream) {
-    AttnArgs a; a.qkv = qkv; a.out = out; a.lse = lse; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;
+    AttnArgs a; a.qkv = qkv; a.out = out; a.lse = lse; a.B = B; a.L = L; a.H = H; a.causal = (causal & 1) != 0;
+    a.tiled_fwd_16 = (causal & 2) != 0;  // 224 < L <= 640: the staged 16-query-block kernel instead of the resident form (A/B, tests)
     return launch_attn_fwd(dtype, a, (hipStream_t)stream);
 }
 extern "C" int mudpt_attention_fwd_exact(const float* qkv32, void* qkv_lp, void* out_hi, void* out_lo, int32_t ld_out, float* lse, int32_t B, int32_t L, int32_t H,

@@ -383,7 +383,9 @@ def test_layernorm_gather_scatter(lib):
 
 ATTN_CASES = [(3, 201, 12, False), (11, 77, 8, True), (2, 7, 3, False), (2, 33, 2, True), (1, 224, 1, False), (2, 64, 2, True),
               # L > 224: the tiled (online-softmax) kernels; 581 = ViT-L/14@336's 577 tokens + 4 prompt rows (BASELINE configs[4])
-              (2, 300, 2, False), (1, 581, 3, False), (2, 260, 2, True), (1, 225, 1, False),
+              # (forward: K and V of a pair resident in LDS up to L = 640, one workgroup per pair; above that the staged 16-query-block form)
+              (2, 300, 2, False), (1, 581, 3, False), (2, 260, 2, True), (1, 225, 1, False), (1, 640, 2, False), (1, 641, 1, False),
+              (2, 513, 2, True), (70, 300, 4, False),
               # more (sequence, head) pairs than resident workgroups: the persistent loops of the forward and the fused backward walk
               # several pairs per workgroup (images of the next pair stream in while the current one is computed)
               (150, 201, 2, False), (700, 20, 8, True)]
@@ -440,6 +442,34 @@ def test_attention_fwd_bwd(lib, dtype, B, L, H, causal):
         ok(lib, lib.mudpt_attention_bwd(dt, P(qc), P(out), P(doc), P(lse), P(delta), P(twice), B, L, H, int(causal) | form, None))
         torch.cuda.synchronize()
         assert torch.equal(twice, other), form
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,L,H,causal,gain", [(2, 581, 3, False, 1.0), (2, 581, 3, False, 3.0), (3, 400, 2, True, 2.5), (1, 640, 1, False, 0.05)])
+def test_attention_long_forward_forms(lib, dtype, B, L, H, causal, gain):
+    """224 < L <= 640: the resident forward (32 queries per wave, rescale deferred until a row's maximum outgrows its reference by 2^6)
+    against the staged 16-query-block kernel (flag bit 1) and the definition.  gain 3: scores of +-100 and more, the reference moves at
+    most steps and by far more than the threshold; gain 0.05: it never moves after the first step."""
+    dt, tt = DT[dtype]
+    g = torch.Generator().manual_seed(L + int(gain * 10))
+    qkv = (torch.randn(B, L, 3 * H * 64, generator=g) * gain)
+    qkv[..., 2 * H * 64:] /= gain  # values stay O(1)
+    qkv = qkv.to(tt)
+    Lp = lib.mudpt_attention_padded_len(L)
+    qc = qkv.cuda()
+    outs, lses = [], []
+    for flag in (0, 2):
+        out = torch.full((B, L, H * 64), float("nan"), device="cuda", dtype=tt)
+        lse = torch.full((B, H, Lp), float("nan"), device="cuda")
+        ok(lib, lib.mudpt_attention_fwd(dt, P(qc), P(out), P(lse), B, L, H, int(causal) | flag, None))
+        torch.cuda.synchronize()
+        outs.append(out.cpu().float()); lses.append(lse.cpu())
+    ref = O.attention(qkv.float(), H, O.causal_mask(L) if causal else None)
+    for out in outs:
+        torch.testing.assert_close(out, ref, atol=6 * EPS[dtype], rtol=6 * EPS[dtype])
+    torch.testing.assert_close(outs[0], outs[1], atol=3 * EPS[dtype], rtol=3 * EPS[dtype])
+    torch.testing.assert_close(lses[0][:, :, :L], lses[1][:, :, :L], atol=2e-4, rtol=1e-5)
+    assert (lses[0][:, :, L:] == 0).all()  # the padded tail the backward reads
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

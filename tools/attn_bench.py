@@ -20,6 +20,7 @@ def main():
         dqkv, lse, delta = torch.empty_like(qkv), torch.zeros(B, H, Lp, device="cuda"), torch.zeros(B, H, Lp, device="cuda")
         fl = 4.0 * B * H * L * L * 64
         for nm, fn, mult in (("fwd", lambda: lib.mudpt_attention_fwd(0, P(qkv), P(out), P(lse), B, L, H, 0, None), 1.0),
+                             ("fwd 16-block tiled", lambda: lib.mudpt_attention_fwd(0, P(qkv), P(out), P(lse), B, L, H, 2, None), 1.0),
                              ("bwd (dQ kernel + dK/dV kernel)", lambda: lib.mudpt_attention_bwd(0, P(qkv), P(out), P(dout), P(lse), P(delta), P(dqkv), B, L, H, 0, None), 3.5)):
             assert fn() == 0
             torch.cuda.synchronize()
