@@ -11,9 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "lib", "libmudpt_hip.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "attention.hip", "attention_single.hip", "attention_exact.hip", "layernorm.hip", "elementwise.hip", "head.hip", "model.cpp"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "attention.hip", "attention_single.hip", "attention_exact.hip", "attention_resident.hip", "layernorm.hip", "elementwise.hip", "head.hip", "model.cpp"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "mudpt.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+EXTRA_FLAGS = {"attention_resident.hip": ["-fno-slp-vectorize"]}  # why: the header of that file
 
 
 def hipcc() -> str:
@@ -40,7 +41,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or _stale(o, [s] + hdrs):
-            jobs.append([cc, *FLAGS, "-x", "hip", "-c", s, "-o", o])
+            jobs.append([cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

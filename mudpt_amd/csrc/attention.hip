@@ -1003,178 +1003,6 @@ __global__ __launch_bounds__(TW * 64) void attn_fwd_tiled_kernel(AttnArgs p, int
     if (g == 0 && p.lse && q < Lp) p.lse[(size_t)pair * Lp + q] = q < L ? m * 0.125f + __logf(l) : 0.f;
 }
 
-// Long-sequence forward, round 3 second form ("resident"): the pair's whole K and V sit in LDS (2 x Lr x 128 bytes, Lr = L rounded up to 32:
-// 152 KB of the CU's 160 KB at L = 581), staged ONCE per (image, head) pair instead of once per 128-query workgroup, and the waves of the
-// one workgroup per CU then stream over them with no barrier at all.  Timing ablations of the staged kernels showed why: with the per-stage
-// global -> register -> LDS copy removed the 16-query-block core ran 18 % faster and the 32-query core below 49 % faster.
-// Each wave owns 32 queries on v_mfma_f32_32x32x16: S^T[32 keys][32 queries] = K Q^T puts ONE query on a lane (column l & 31) with 16 of the
-// tile's 32 keys in its registers (rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)); the other 16 sit in lane l ^ 32, so the row maximum / sum need
-// one cross-lane exchange per 64 keys instead of two per 16-query block, a 32 x 32 tile costs half the MFMA and LDS-read instructions of
-// two 16 x 16 x 32 blocks, and registers 8 s .. 8 s + 7 of a tile, packed to T, ARE the B operand of O^T = V^T P^T for the 16-key slab s
-// (the k order inside a slab is rows 16 s + 8 (j >> 2) + 4 h + (j & 3): the A operand follows it by reading V with two hardware-transposed
-// 4 x 16 block reads at rows 16 s + 4 h and 16 s + 8 + 4 h).  Query blocks are dealt round-robin to the RES_W-or-fewer waves.
-// LDS images are [Lr keys][64] with 16-byte chunk c of row r in slot c ^ fK(r) / c ^ fV(r): fK(r) = (r >> 1) & 7 is conflict-free for the
-// 32-row ds_read_b128 fragments, fV(r) = bits (0, 1, 2) of r sent to bits (0, 2, 1) for the transposed 64-bit block reads (brute-force
-// checked against the bank maps of MI355X_MICROARCH.md's LDS table).
-__device__ inline int flash_fk(int r) { return (r >> 1) & 7; }
-__device__ inline int flash_fv(int r) { return (r & 1) | ((r & 2) << 1) | ((r & 4) >> 1); }
-constexpr int RES_W_MAX = 16;               // launch bound (128 VGPRs: the build bounded at 12 waves / 168 VGPRs measured 17 % slower at 12 waves)
-constexpr int RES_W = 12;                   // waves launched at most: 3 per SIMD; 19 query blocks (L = 581) then load the SIMDs 5 / 5 / 5 / 4
-constexpr float RES_DEFER = 6.f;            // deferred rescale threshold, base-2 exponent units
-constexpr int RES_LDS_MAX = 160 * 1024;     // gfx950: one workgroup may own the CU's whole LDS
-
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(RES_W_MAX * 64) void attn_fwd_resident_kernel(AttnArgs p) {
-    using elem = typename T::elem;
-    using vec8 = typename T::vec8;
-    using vec4 = typename T::vec4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char res_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5, nthr = blockDim.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
-    const int pair = blockIdx.x, b = pair / p.H, hd = pair - b * p.H;
-    const int HD = p.H * 64, L = p.L, Lp = attn_padded_len_dev(L), Lr = (L + 31) & ~31;
-    elem* Ks = (elem*)res_lds;
-    elem* Vs = Ks + (size_t)Lr * 64;
-    const size_t ld = (size_t)3 * HD;
-    const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
-    // stage the pair: Lr rows x 8 chunks of K and of V, four chunks of each in flight per thread; rows >= L are zero
-    for (int i0 = tid; i0 < Lr * 8; i0 += 4 * nthr) {
-        vec8 sk[4], sv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = i0 + k * nthr, row = idx >> 3, ch = idx & 7;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { sk[k][i] = (elem)0.f; sv[k][i] = (elem)0.f; }
-            if (row < L) {
-                sk[k] = *(const vec8*)(base + HD + (size_t)row * ld + ch * 8);
-                sv[k] = *(const vec8*)(base + 2 * HD + (size_t)row * ld + ch * 8);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = i0 + k * nthr, row = idx >> 3, ch = idx & 7;
-            if (row < Lr) {
-                *(vec8*)(Ks + row * 64 + ((ch ^ flash_fk(row)) << 3)) = sk[k];
-                *(vec8*)(Vs + row * 64 + ((ch ^ flash_fv(row)) << 3)) = sv[k];
-            }
-        }
-    }
-    __syncthreads();  // the only barrier: K and V are read-only from here on
-    const int gp = (lane >> 4) & 1, i16 = lane & 15;
-    const int nqb = (L + 31) >> 5, ntile = Lr >> 5;
-    const size_t ldo = p.ld_out ? (size_t)p.ld_out : (size_t)HD;
-    for (int qb = wave; qb < nqb; qb += nw) {
-        const int q0 = qb * 32, q = q0 + n;
-        vec8 qf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) qf[ks][i] = (elem)0.f;
-            if (q < L) qf[ks] = *(const vec8*)(base + (size_t)q * ld + 16 * ks + 8 * h);
-        }
-        f32x16 O[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
-        float m = -INFINITY, l = 0.f;
-        const int tend = CAUSAL ? (qb + 1 < ntile ? qb + 1 : ntile) : ntile;  // 32-key tiles this block sees
-        // NT = 2: a 64-key step (one maximum / rescale for two tiles); NT = 1: the odd tile at the end
-        auto step = [&](auto nt_c, int t0) {
-            constexpr int NT = decltype(nt_c)::value;
-            const int key0 = t0 * 32;
-            f32x16 S[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) S[t][r] = 0.f;
-                const int row = key0 + 32 * t + n;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    S[t] = T::mfma32(*(const vec8*)(Ks + row * 64 + (((2 * ks + h) ^ flash_fk(row)) << 3)), qf[ks], S[t]);
-            }
-            if (CAUSAL || key0 + 32 * NT > L) {  // only the step that holds the end of the sequence (and causal steps) needs the per-key mask
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = key0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (key >= L || (CAUSAL && key > q)) S[t][r] = -INFINITY;
-                    }
-            }
-            float mloc = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, S[t][r]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float mnew = fmaxf(m, mloc);  // finite from the first step on: key 0 is visible to every query
-            // Deferred rescale: m is the REFERENCE of the exponentials, not necessarily the running maximum.  It moves (and l and O are
-            // rescaled, 34 multiplies) only when some row of the wave outgrew it by more than 2^RES_DEFER; until then p <= 2^RES_DEFER, exact
-            // in fp32 and at the same relative precision in T.  The first step (m = -inf) always takes the branch.
-            if (__builtin_amdgcn_ballot_w64((mnew - m) * SC > RES_DEFER) != 0) {
-                const float alpha = mnew == -INFINITY ? 1.f : __builtin_amdgcn_exp2f((m - mnew) * SC);
-                m = mnew;
-                l *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) O[dt] *= alpha;
-            }
-            const float nm = m == -INFINITY ? 0.f : -m * SC;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][r], SC, nm));
-                    S[t][r] = e;
-                    l += e;
-                }
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    vec8 pb;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pb[j] = (elem)S[t][8 * sl + j];
-                    const int rr = key0 + 32 * t + 16 * sl + 4 * h + (i16 >> 2);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const int col = 32 * dt + 16 * gp + 4 * (i16 & 3);
-                        const elem* vp = Vs + rr * 64 + ((((col >> 3) ^ flash_fv(rr)) << 3) + (col & 7));
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vp);
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 8 * 64));
-                        typedef __attribute__((ext_vector_type(8))) short s16x8;
-                        const vec8 vf = __builtin_bit_cast(vec8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                        O[dt] = T::mfma32(vf, pb, O[dt]);
-                    }
-                }
-        };
-        int t0 = 0;
-        for (; t0 + 2 <= tend; t0 += 2) step(std::integral_constant<int, 2>{}, t0);
-        if (t0 < tend) step(std::integral_constant<int, 1>{}, t0);
-        l += __shfl_xor(l, 32, 64);
-        if (q < L) {
-            const float inv = 1.f / l;
-            const size_t off = ((size_t)b * L + q) * ldo + hd * 64;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int d0 = 32 * dt + 8 * rr + 4 * h;  // registers 4 rr .. 4 rr + 3 of tile dt are d0 .. d0 + 3 of this lane's query
-                    vec4 hv, lv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        elem a, c;
-                        split_hi_lo(O[dt][4 * rr + e] * inv, a, c);
-                        hv[e] = a; lv[e] = c;
-                    }
-                    *(vec4*)((elem*)p.out + off + d0) = hv;
-                    if (p.out_lo) *(vec4*)((elem*)p.out_lo + off + d0) = lv;
-                }
-        }
-        if (h == 0 && p.lse && q < Lp) p.lse[(size_t)pair * Lp + q] = q < L ? m * 0.125f + __logf(l) : 0.f;
-    }
-}
-
 template <typename T, bool CAUSAL>
 __global__ __launch_bounds__(TW * 64) void attn_bwd_dq_tiled_kernel(AttnArgs p, const void* fwd_out, int nsb) {
     using A = Attn<T>;
@@ -1357,22 +1185,14 @@ static int tiled_launch(const AttnArgs& a, hipStream_t s, const LaunchProf* prof
     ARG_CHECK(nwg < 0x7fffffffull, "attention: too many workgroups (%zu)", nwg);
     const dim3 grid((unsigned)nwg), block(TW * 64);
     if (!BWD) {
-        const int Lr = (a.L + 31) & ~31, lds = Lr * 64 * 2 * (int)sizeof(typename T::elem);
-        if (!a.tiled_fwd_16 && lds <= RES_LDS_MAX) {  // K and V of a pair fit one CU's LDS (L <= 640): the resident form, one workgroup per pair
-            const int nqb = Lr / 32, nwv = nqb <= RES_W_MAX ? nqb : RES_W;  // one round if the blocks fit the workgroup, else 3 waves per SIMD
-            static PerDevice pd[2];
-            const int dev = current_device();
-            if (!pd[a.causal].done[dev]) {
-                const void* k = a.causal ? (const void*)attn_fwd_resident_kernel<T, true> : (const void*)attn_fwd_resident_kernel<T, false>;
-                HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS_MAX));
-                pd[a.causal].done[dev] = true;
-            }
-            if (a.causal) MUDPT_LAUNCH((attn_fwd_resident_kernel<T, true>), dim3(a.B * a.H), dim3(nwv * 64), lds, s, prof, a);
-            else MUDPT_LAUNCH((attn_fwd_resident_kernel<T, false>), dim3(a.B * a.H), dim3(nwv * 64), lds, s, prof, a);
+        if (!a.tiled_fwd_16 && attn_resident_fits(a.L, false)) {  // K and V of a pair fit one CU's LDS (L <= 640): one workgroup per pair
+            return launch_attn_fwd_resident(T::id, a, s, prof);
         } else {  // the staged 16-query-block form
             if (a.causal) MUDPT_LAUNCH((attn_fwd_tiled_kernel<T, true>), grid, block, 0, s, prof, a, nsb);
             else MUDPT_LAUNCH((attn_fwd_tiled_kernel<T, false>), grid, block, 0, s, prof, a, nsb);
         }
+    } else if (!a.two_kernels && !a.sel_rows && a.win_n <= 0 && attn_resident_fits(a.L, true)) {
+        return launch_attn_bwd_resident(T::id, a, s, prof);
     } else {
         if (a.causal) {
             MUDPT_LAUNCH((attn_bwd_dq_tiled_kernel<T, true>), grid, block, 0, s, &p1, a, (const void*)a.out, nsb);

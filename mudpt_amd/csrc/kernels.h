@@ -129,6 +129,10 @@ int launch_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s, const LaunchPro
 // Exact-fp32 forward (the "fp32" mode): reads a.qkv32, writes a.out (fp16 hi) + a.out_lo (fp16 lo, optional) + a.lse and, if a.qkv_lp
 // is set, the fp16 copy of q, k, v that the backward kernels read.
 int launch_attn_fwd_exact(const AttnArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);
+// attention_resident.hip: both streamed operands of a (sequence, head) pair resident in LDS (224 < L, Lr * 256 (+ 8 Lr backward) <= 160 KB)
+bool attn_resident_fits(int L, bool bwd);
+int launch_attn_fwd_resident(int dtype, const AttnArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);
+int launch_attn_bwd_resident(int dtype, const AttnArgs& a, hipStream_t s, const LaunchProf* prof = nullptr);  // dQ (+ delta) kernel, then dK/dV kernel
 
 // ------------------------------------------------------------------------------------------------
 // Small / HBM-bound helpers
