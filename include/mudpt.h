@@ -168,7 +168,9 @@ int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* hos
  *
  *   knob               default         meaning
  *   gemm_variant       0               kernel choice of the MFMA GEMMs (gemm.hip launch_epi / gemm_pp.hip; 0 = the default dispatch)
- *   split_k            1               0 = never split the contraction of the small-grid, long-K backward GEMMs
+ *   split_k            1               0 = never split the contraction of the vision tower's small-grid, long-K store GEMMs
+ *   fwd_split_k        1               0 = ... of the forward ones (out_proj / c_proj up to 320 tiles of 64 x 64, i.e. <= 8 images of ViT-B): logits
+ *                                      of a batch then equal the logits of its chunks bit for bit at EVERY chunk size (default: above that size)
  *   attn_window        1               0 = block 0's attention backward on all rows instead of the prompt rows' blocks
  *   last_single        1 (0 exact)     0 = the last block's attention on all rows instead of the single-query form
  *   attn_two_kernels   0               1 = attention backward as the dQ + dK/dV kernel pair

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(RES_W_BWD * 64) void attn_bwd_dkv_resident_kernel(A
 // ------------------------------------------------------------------------------------------------
 bool attn_resident_fits(int L, bool bwd) {
     const int Lr = (L + 31) & ~31;
-    return L > 224 && Lr * (256 + (bwd ? 8 : 0)) <= RES_LDS_MAX;
+    return L > 224 && Lr * (256 + (bwd ? 8 : 0)) <= RES_LDS_MAX;  // L <= 224: the whole-pair kernels of attention.hip (resident forms measured 28 / 52 % slower at L = 201)
 }
 
 template <typename T>

@@ -195,6 +195,9 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return MUDPT_OK;
 }
 
+constexpr size_t SMALL_T64 = 3200;
+static inline bool small_tiles(const GemmArgs& a) { return (size_t)((a.M + 63) / 64) * ((a.N + 63) / 64) <= SMALL_T64; }
+
 // variant: tuning knob (mudpt_model_set "gemm_variant" / mudpt_gemm's last argument): 0 = default kernel choice, 1/2/4 = force a simple tile
 template <typename T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, int variant) {
@@ -211,6 +214,11 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, int variant) {
     // workgroups) and a 4-deep ring.  gemm_variant 5 / 6 force the shallow / deep form (A/B runs).
     const size_t t128 = (size_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const int v = variant & 0xff;
+    // Round 3: up to SMALL_T64 64 x 64 tiles (M = 804 at the reference's training batch of 4, the text tower up to ~6000 rows) a 64 x 64
+    // tile on 4 waves with the plain double buffer wins on every shape measured (tools/gemm_bench.py --set small / text: sum of a block's
+    // GEMMs 217 -> 167 us at M = 804): 32 KB of LDS lets five workgroups share a CU, and these grids are latency chains, not MFMA-bound.
+    // gemm_variant 5 / 6 force the earlier 128 x 128 shallow / 128 x 64 deep forms, 9 this one (A/B runs).
+    if ((v == 0 && small_tiles(a)) || v == 9) return launch_cfg<T, 64, 64, 2, 2, EPI, 2>(a, s);
     if ((t128 <= 128 && v != 5) || v == 6) return launch_cfg<T, 128, 64, 2, 2, EPI, 4>(a, s);
     return launch_cfg<T, 128, 128, 2, 2, EPI>(a, s);
 }
@@ -259,9 +267,9 @@ static int split_k_slices(int epi, const GemmArgs& a, const GemmOpts& o) {
         if (hipDeviceGetAttribute(&pd.ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
         pd.done[dev] = true;
     }
-    const size_t tiles = (size_t)((a.M + 127) / 128) * ((a.N + 63) / 64);
-    if (tiles * 2 > (size_t)pd.ncu[dev] || a.K < 1536) return 1;
-    int S = (int)((size_t)pd.ncu[dev] / tiles);
+    const size_t tiles = (size_t)((a.M + 63) / 64) * ((a.N + 63) / 64);  // 64 x 64 tiles, five workgroups to a CU
+    if (tiles * 2 > (size_t)pd.ncu[dev] * 5 || a.K < 1536) return 1;
+    int S = (int)((size_t)pd.ncu[dev] * 5 / tiles);
     if (S > 4) S = 4;
     while (S > 1 && (a.K % (S * 64) != 0 || a.K / S < 512)) --S;
     if ((size_t)S * a.M * a.N > o.scratch_elems) return 1;
@@ -297,8 +305,8 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const Gemm
     if (const int S = split_k_slices(epi, a, o); S > 1) {
         GemmArgs q = b;
         q.bias = nullptr; q.out0 = o.scratch; q.ldo0 = a.N; q.ksplit = a.K / S; q.split_stride = (size_t)a.M * a.N;
-        if (dtype == DT_BF16) { if (int rc = launch_cfg<BF16, 128, 64, 2, 2, EPI_STORE_F32, 4>(q, s)) return rc; }
-        else if (dtype == DT_F16) { if (int rc = launch_cfg<F16, 128, 64, 2, 2, EPI_STORE_F32, 4>(q, s)) return rc; }
+        if (dtype == DT_BF16) { if (int rc = launch_cfg<BF16, 64, 64, 2, 2, EPI_STORE_F32, 2>(q, s)) return rc; }
+        else if (dtype == DT_F16) { if (int rc = launch_cfg<F16, 64, 64, 2, 2, EPI_STORE_F32, 2>(q, s)) return rc; }
         else { set_error("gemm: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
         const unsigned grid = (unsigned)(((size_t)a.M * (a.N / 4) + 255) / 256);
         if (epi == EPI_STORE_F32) hipLaunchKernelGGL((splitk_reduce_kernel<BF16, true>), dim3(grid), dim3(256), 0, s, o.scratch, S, q.split_stride, a.M, a.N, a.bias, a.out0, a.ldo0);

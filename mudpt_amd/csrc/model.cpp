@@ -194,6 +194,8 @@ struct mudpt_model {
     int txt_buckets = 3;   // knob: at most this many length buckets for the class prompts (1 = every prompt runs to the longest EOT)
     bool attn_fused_w1 = false;
     bool split_k = true;      // knob: split K for the small-grid, long-K store GEMMs (small batches)
+    bool fwd_split_k = true;  // knob: ... of the forward too, up to kFwdSplitTiles tiles (gemm_call)
+    static constexpr size_t kFwdSplitTiles = 320;
     static constexpr size_t kScratchElems = (size_t)4 << 20;  // 4 slices x 128 tiles of 128 x 64 fp32
     float *gemm_scratch = nullptr, *gemm_scratch2 = nullptr;
     bool attn_window = true;  // knob: block 0's attention backward computes the 16-row blocks of the prompt rows only (0 = all rows)
@@ -240,15 +242,21 @@ static int prof_next(mudpt_model* m, int cls, double work, LaunchProf* out) {
 
 // Every MFMA GEMM of the path goes through here; with profiling on, the launch is bracketed by HIP events on
 // the launch stream and its algorithmic FLOPs (2 M N K) are recorded.
-// bwd: a GEMM of the backward pass.  Only those may split K: a split sum has a different fp32 association than the sequential one, and
-// whether a shape splits depends on M -- forward results must not depend on how a batch is chunked (logits of a batch equal the
-// logits of its chunks bit for bit: a tested property), gradients are only held to agree to rounding.
-static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s, bool bwd = false) {
+// bwd: a GEMM of the backward pass.  Those may always split K; a FORWARD GEMM only where the caller allows it (fwd_split: the vision
+// tower's out_proj / c_proj outside the exact mode) and its grid is at most kFwdSplitTiles 64 x 64 tiles (ViT-B: up to 8 images -- the
+// reference's own training batch of 4, where c_proj's 48-step chain on 156 workgroups was the longest kernel of the step).  The text
+// tower never splits, forward or backward (its call sites pass bwd = !t.causal): its features are bit-identical and its gradients equal to
+// the order of the fp32 sums over classes however the class prompts are bucketed (a tested property; a split decision that depends on the
+// row count of a bucketing moved the fp16 gradients by 1e-2 of their rms, the size of the fp16 backward's whole rounding noise).  A split sum has a different fp32 association than the sequential one and whether a shape splits depends on M, so the
+// tested property "logits of a batch equal the logits of its chunks bit for bit" holds for chunks ABOVE that size (knob fwd_split_k = 0
+// restores it for every size); gradients are only held to agree to rounding.
+static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s, bool bwd = false, bool fwd_split = false) {
     // only the dominant kernel is bracketed: gemm_pp_kernel launches (the vision tower's big GEMMs, main stream).  The text
     // tower's small GEMMs run on the side stream, where an event pair would mostly measure queueing behind the other stream.
     GemmOpts o;
     o.variant = m->gemm_variant;
-    if (m->split_k && bwd) {  // split-K partials: one scratch per stream (the towers run concurrently)
+    const bool fwd_small = fwd_split && m->fwd_split_k && (size_t)((a.M + 63) / 64) * ((a.N + 63) / 64) <= mudpt_model::kFwdSplitTiles;
+    if (m->split_k && (bwd || fwd_small)) {  // split-K partials: one scratch per stream (the towers run concurrently)
         o.scratch = s == m->s2 ? m->gemm_scratch2 : m->gemm_scratch;
         o.scratch_elems = mudpt_model::kScratchElems;
     }
@@ -924,7 +932,8 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
     }
     if (i + 1 == t.layers) return block_fwd_tail(m, t, nseq, s);
     GemmArgs o; o.A = a.attn; o.lda = sp * d; o.B = t.split ? w.w_out2 : w.w_out; o.ldb = sp * d; o.M = M; o.N = d; o.K = sp * d; o.bias = w.b_out; o.out0 = t.upd; o.ldo0 = d;
-    TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, o, s));
+    const bool fs = !t.causal && !t.exact;  // forward split K: the vision tower's out_proj / c_proj at tiny batches only (gemm_call)
+    TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, o, s, false, fs));
     LnFwdArgs l2; l2.x = a.x_in; l2.ldx = d; if (lp) l2.add_lp = t.upd; else l2.add = t.upd; l2.ldadd = d; l2.xout = a.x_mid; l2.ldxout = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = sp * d;
     if (t.split) l2.out_lo = (char*)t.h + (size_t)d * esz;
     l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = M; l2.d = d;
@@ -934,7 +943,7 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
     if (t.split) f.out1_lo = (char*)t.g + (size_t)4 * d * esz;
     TRY(gemm_call(m, EPI_GELU, f, s));
     GemmArgs p; p.A = t.g; p.lda = sp * 4 * d; p.B = t.split ? w.w_proj2 : w.w_proj; p.ldb = sp * 4 * d; p.M = M; p.N = d; p.K = sp * 4 * d; p.bias = w.b_proj; p.out0 = t.upd; p.ldo0 = d;
-    TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, p, s));
+    TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, p, s, false, fs));
     return MUDPT_OK;
 }
 
@@ -947,15 +956,15 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
     GemmArgs g1; g1.A = t.dsel_lp; g1.lda = d; g1.B = w.w_proj_t; g1.ldb = d; g1.M = S; g1.N = 4 * d; g1.K = d; g1.out0 = t.g_sel; g1.ldo0 = 4 * d; g1.aux = t.u_sel; g1.ldaux = 4 * d;
-    TRY(gemm_call(m, EPI_GELU_BWD, g1, s, true));
+    TRY(gemm_call(m, EPI_GELU_BWD, g1, s, !t.causal));
     GemmArgs g2; g2.A = t.g_sel; g2.lda = 4 * d; g2.B = w.w_fc_t; g2.ldb = 4 * d; g2.M = S; g2.N = d; g2.K = 4 * d; g2.out0 = t.h_sel; g2.ldo0 = d;
-    TRY(gemm_call(m, EPI_STORE, g2, s, true));
+    TRY(gemm_call(m, EPI_STORE, g2, s, !t.causal));
     LnBwdArgs b2; b2.dy = t.h_sel; b2.lddy = d; b2.x = t.xmid_sel; b2.ldx = d; b2.mean = a.mean2; b2.rstd = a.rstd2; b2.gamma = w.ln2_g; b2.lddres = d;
     if (m->lp_grad) b2.dres_lp = t.dsel_lp; else { b2.dres = t.dsel; b2.dx = t.dsel; }
     b2.lddx = d; b2.dx_lp = t.dsel_lp; b2.lddx_lp = d; b2.rows = S; b2.d = d;
     TRY(launch_ln_bwd(dt, b2, s));  // t.dsel(_lp) = gradient w.r.t. x_mid on the selected rows
     GemmArgs g3; g3.A = t.dsel_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = S; g3.N = d; g3.K = d; g3.out0 = t.dattn_sel; g3.ldo0 = d;
-    TRY(gemm_call(m, EPI_STORE, g3, s, true));
+    TRY(gemm_call(m, EPI_STORE, g3, s, !t.causal));
     if (m->last_single) {
         // single-query attention backward: dK, dV of every row (k, v thirds of t.dqkv) and dq of the one query per sequence
         const int spd = (t.split ? 2 : 1) * d;
@@ -970,9 +979,9 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
         // d(ln_1 output) = dK, dV rows . W_kv  (K range d .. 3d of the transposed in_proj weight)  +  on the selected rows  dq . W_q
         GemmArgs g4; g4.A = (char*)t.dqkv + (size_t)d * esz; g4.lda = 3 * d; g4.B = (char*)w.w_in_t + (size_t)d * esz; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 2 * d;
         g4.out0 = t.h; g4.ldo0 = d;
-        TRY(gemm_call(m, EPI_STORE, g4, s, true));
+        TRY(gemm_call(m, EPI_STORE, g4, s, !t.causal));
         GemmArgs g5; g5.A = t.dq_sel; g5.lda = d; g5.B = w.w_in_t; g5.ldb = 3 * d; g5.M = S; g5.N = d; g5.K = d; g5.out0 = t.dqx_sel; g5.ldo0 = d;
-        TRY(gemm_call(m, EPI_STORE, g5, s, true));
+        TRY(gemm_call(m, EPI_STORE, g5, s, !t.causal));
         TRY(launch_add_rows(dt, t.dqx_sel, t.tail_rows, t.h, S, d, s));
     } else {
     // attention backward over all keys: d(attention output) is zero except on the selected query rows
@@ -988,7 +997,7 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
         TRY(attn_call(m, t, at, true, s));
     }
     GemmArgs g4; g4.A = t.dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 3 * d; g4.out0 = t.h; g4.ldo0 = d;
-    TRY(gemm_call(m, EPI_STORE, g4, s, true));
+    TRY(gemm_call(m, EPI_STORE, g4, s, !t.causal));
     }
     // the residual path into ln_1's input: d(x_mid), zero except on the selected rows
     HIP_TRY(hipMemsetAsync(t.dx_lp, 0, (size_t)M * d * esz, s));
@@ -1012,15 +1021,15 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s, f
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
     GemmArgs g1; g1.A = t.dx_lp; g1.lda = d; g1.B = w.w_proj_t; g1.ldb = d; g1.M = M; g1.N = 4 * d; g1.K = d; g1.out0 = t.g; g1.ldo0 = 4 * d; g1.aux = a.u; g1.ldaux = 4 * d;
-    TRY(gemm_call(m, EPI_GELU_BWD, g1, s, true));
+    TRY(gemm_call(m, EPI_GELU_BWD, g1, s, !t.causal));
     GemmArgs g2; g2.A = t.g; g2.lda = 4 * d; g2.B = w.w_fc_t; g2.ldb = 4 * d; g2.M = M; g2.N = d; g2.K = 4 * d; g2.out0 = t.h; g2.ldo0 = d;
-    TRY(gemm_call(m, EPI_STORE, g2, s, true));
+    TRY(gemm_call(m, EPI_STORE, g2, s, !t.causal));
     LnBwdArgs b2; b2.dy = t.h; b2.lddy = d; b2.x = a.x_mid; b2.ldx = d; b2.mean = a.mean2; b2.rstd = a.rstd2; b2.gamma = w.ln2_g; b2.lddres = d;
     if (m->lp_grad) b2.dres_lp = t.dx_lp; else { b2.dres = t.dx; b2.dx = t.dx; }
     b2.lddx = d; b2.dx_lp = t.dx_lp; b2.lddx_lp = d; b2.rows = M; b2.d = d;
     TRY(ln_bwd_call(m, t, b2, s));
     GemmArgs g3; g3.A = t.dx_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = M; g3.N = d; g3.K = d; g3.out0 = t.dattn; g3.ldo0 = d;
-    TRY(gemm_call(m, EPI_STORE, g3, s, true));
+    TRY(gemm_call(m, EPI_STORE, g3, s, !t.causal));
     for (const Tower::Seg& g : tower_segs(t, nseq)) {
         const size_t esz = 2, spd = (size_t)(t.split ? 2 : 1) * d;
         AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * spd * esz; at.lse = a.lse + g.lse0;
@@ -1037,7 +1046,7 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s, f
         const int R = nseq * t.head_n;
         TRY(launch_gather_rows(t.dqkv, (size_t)3 * d * 2, t.head_rows, t.hd_dqkv, (size_t)3 * d * 2, R, 3 * d * 2, s));
         GemmArgs g4; g4.A = t.hd_dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = R; g4.N = d; g4.K = 3 * d; g4.out0 = t.hd_h; g4.ldo0 = d;
-        TRY(gemm_call(m, EPI_STORE, g4, s, true));
+        TRY(gemm_call(m, EPI_STORE, g4, s, !t.causal));
         LnBwdArgs b1; b1.dy = t.hd_h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.row_index = t.head_rows; b1.stats_by_token = true;
         b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.lddres = d;
         if (m->lp_grad) b1.dres_lp = t.dx_lp; else { b1.dres = t.dx; b1.dx = t.dx; }
@@ -1046,7 +1055,7 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s, f
         return MUDPT_OK;
     }
     GemmArgs g4; g4.A = t.dqkv; g4.lda = 3 * d; g4.B = w.w_in_t; g4.ldb = 3 * d; g4.M = M; g4.N = d; g4.K = 3 * d; g4.out0 = t.h; g4.ldo0 = d;
-    TRY(gemm_call(m, EPI_STORE, g4, s, true));
+    TRY(gemm_call(m, EPI_STORE, g4, s, !t.causal));
     LnBwdArgs b1; b1.dy = t.h; b1.lddy = d; b1.x = a.x_in; b1.ldx = d; b1.mean = a.mean1; b1.rstd = a.rstd1; b1.gamma = w.ln1_g; b1.lddres = d;
     if (m->lp_grad) b1.dres_lp = t.dx_lp; else { b1.dres = t.dx; b1.dx = t.dx; }
     b1.lddx = d; b1.dx_lp = t.dx_lp; b1.lddx_lp = d; b1.rows = M; b1.d = d;
@@ -1544,6 +1553,7 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
     if (!strcmp(name, "lp_upd")) { m->lp_upd = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "txt_trim")) { m->txt_trim = value != 0; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
     if (!strcmp(name, "attn_two_kernels")) { m->attn_two_kernels = value != 0; return MUDPT_OK; }
+    if (!strcmp(name, "fwd_split_k")) { m->fwd_split_k = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "attn_fused_w1")) { m->attn_fused_w1 = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "split_k")) { m->split_k = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "attn_window")) { m->attn_window = value != 0; return MUDPT_OK; }

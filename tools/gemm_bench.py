@@ -27,6 +27,11 @@ TEXT_SHAPES = [(f"{nm} M={M}", M, N, K, e) for M in (99, 6336, 19000)
                for nm, N, K, e in (("qkv", 1536, 512, 0), ("out", 512, 512, 5), ("fc", 2048, 512, 1), ("proj", 512, 2048, 5))]
 
 
+# the reference's own training batch (B 4: M = 4 x 201 = 804 rows) and the 50-class text tower beside it (50 prompts x ~20 positions)
+SMALL_SHAPES = [(f"{nm} M={M}", M, N, K, e) for M, w in ((804, 768), (1000, 512))
+                for nm, N, K, e in (("qkv", 3 * w, w, 0), ("out", w, w, 5), ("fc", 4 * w, w, 1), ("proj", w, 4 * w, 5), ("dgelu", 4 * w, w, 3), ("dfc", w, 4 * w, 0), ("dqkv", w, 3 * w, 0))]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
@@ -35,11 +40,11 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--epi", type=int, default=-1, help="only the shapes with this epilogue")
-    ap.add_argument("--set", default="vision", choices=["vision", "text"])
+    ap.add_argument("--set", default="vision", choices=["vision", "text", "small"])
     ap.add_argument("--library-ref", action="store_true", help="also time torch.nn.functional.linear (rocBLAS / hipBLASLt) on the same operands: a "
                     "known-good reference for what this GPU does on the shape (diagnostic only; the product never calls it)")
     a = ap.parse_args()
-    shapes = SHAPES if a.set == "vision" else TEXT_SHAPES
+    shapes = {"vision": SHAPES, "text": TEXT_SHAPES, "small": SMALL_SHAPES}[a.set]
     lib = capi.load()
     dt, tt = (0, torch.bfloat16) if a.dtype == "bf16" else (1, torch.float16)
     variants = [int(v) for v in a.variants.split(",")]
