@@ -34,7 +34,7 @@ __device__ inline int flash_fk(int r) { return (r >> 1) & 7; }
 __device__ inline int flash_fv(int r) { return (r & 1) | ((r & 2) << 1) | ((r & 4) >> 1); }
 constexpr int RES_W_MAX = 16;               // launch bound (128 VGPRs: the build bounded at 12 waves / 168 VGPRs measured 17 % slower at 12 waves)
 constexpr int RES_W = 12;                   // waves launched at most: 3 per SIMD; 19 query blocks (L = 581) then load the SIMDs 5 / 5 / 5 / 4
-constexpr int RES_W_BWD = 8;                // backward kernels: 2 waves per SIMD with 256 VGPRs each (at 168 the compiler serialises every LDS read
+constexpr int RES_W_BWD = 8;                // dK/dV kernel: 2 waves per SIMD with 256 VGPRs each (at 168 the compiler serialises every LDS read
                                             // behind its MFMA); 19 blocks load the SIMDs 5 / 5 / 5 / 4 as with 12 waves
 constexpr float RES_DEFER = 6.f;            // deferred rescale threshold, base-2 exponent units
 constexpr int RES_LDS_MAX = 160 * 1024;     // gfx950: one workgroup may own the CU's whole LDS
@@ -256,7 +256,7 @@ __device__ inline void res_store_t(typename T::elem* dst, const f32x16 (&acc)[2]
 }
 
 template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(RES_W_BWD * 64) void attn_bwd_dq_resident_kernel(AttnArgs p, const void* fwd_out) {
+__global__ __launch_bounds__(RES_W * 64) void attn_bwd_dq_resident_kernel(AttnArgs p, const void* fwd_out) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char res_lds[];
@@ -454,7 +454,7 @@ template <typename T>
 static int bwd_resident(const AttnArgs& a, hipStream_t s, const LaunchProf* prof) {
     const LaunchProf p1{prof ? prof->start : nullptr, nullptr}, p2{nullptr, prof ? prof->stop : nullptr};
     const int Lr = (a.L + 31) & ~31, lds1 = Lr * 256, lds2 = Lr * (256 + 8), nb = Lr / 32;
-    const int nw = nb <= RES_W_BWD ? nb : RES_W_BWD;
+    const int nw1 = nb <= RES_W ? nb : RES_W, nw2 = nb <= RES_W_BWD ? nb : RES_W_BWD;  // dQ: 164 VGPRs fit three waves per SIMD
     static PerDevice pd[2];
     const int dev = current_device();
     if (!pd[a.causal].done[dev]) {
@@ -466,11 +466,11 @@ static int bwd_resident(const AttnArgs& a, hipStream_t s, const LaunchProf* prof
     }
     const dim3 gp(a.B * a.H);
     if (a.causal) {
-        MUDPT_LAUNCH((attn_bwd_dq_resident_kernel<T, true>), gp, dim3(nw * 64), lds1, s, &p1, a, (const void*)a.out);
-        MUDPT_LAUNCH((attn_bwd_dkv_resident_kernel<T, true>), gp, dim3(nw * 64), lds2, s, &p2, a);
+        MUDPT_LAUNCH((attn_bwd_dq_resident_kernel<T, true>), gp, dim3(nw1 * 64), lds1, s, &p1, a, (const void*)a.out);
+        MUDPT_LAUNCH((attn_bwd_dkv_resident_kernel<T, true>), gp, dim3(nw2 * 64), lds2, s, &p2, a);
     } else {
-        MUDPT_LAUNCH((attn_bwd_dq_resident_kernel<T, false>), gp, dim3(nw * 64), lds1, s, &p1, a, (const void*)a.out);
-        MUDPT_LAUNCH((attn_bwd_dkv_resident_kernel<T, false>), gp, dim3(nw * 64), lds2, s, &p2, a);
+        MUDPT_LAUNCH((attn_bwd_dq_resident_kernel<T, false>), gp, dim3(nw1 * 64), lds1, s, &p1, a, (const void*)a.out);
+        MUDPT_LAUNCH((attn_bwd_dkv_resident_kernel<T, false>), gp, dim3(nw2 * 64), lds2, s, &p2, a);
     }
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;

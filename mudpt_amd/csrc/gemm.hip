@@ -195,8 +195,13 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return MUDPT_OK;
 }
 
-constexpr size_t SMALL_T64 = 3200;
-static inline bool small_tiles(const GemmArgs& a) { return (size_t)((a.M + 63) / 64) * ((a.N + 63) / 64) <= SMALL_T64; }
+// 64 x 64 tiles while they are all resident at once (five workgroups per CU x 256 CUs), or twice that for the short contractions of the
+// width-512 text tower; beyond that the 128 x 128 tile's halved operand traffic wins (tools/gemm_bench.py --set small: M = 9 000 / 15 000,
+// N = 768: 48.5 vs 61.2 and 80.2 vs 107.8 us at K = 3072)
+static inline bool small_tiles(const GemmArgs& a) {
+    const size_t t64 = (size_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    return t64 <= 1280 || (t64 <= 2560 && a.K <= 512);
+}
 
 // variant: tuning knob (mudpt_model_set "gemm_variant" / mudpt_gemm's last argument): 0 = default kernel choice, 1/2/4 = force a simple tile
 template <typename T, int EPI>
@@ -214,7 +219,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, int variant) {
     // workgroups) and a 4-deep ring.  gemm_variant 5 / 6 force the shallow / deep form (A/B runs).
     const size_t t128 = (size_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const int v = variant & 0xff;
-    // Round 3: up to SMALL_T64 64 x 64 tiles (M = 804 at the reference's training batch of 4, the text tower up to ~6000 rows) a 64 x 64
+    // Round 3: on small grids (small_tiles: M = 804 at the reference's training batch of 4, the text tower up to ~6000 rows) a 64 x 64
     // tile on 4 waves with the plain double buffer wins on every shape measured (tools/gemm_bench.py --set small / text: sum of a block's
     // GEMMs 217 -> 167 us at M = 804): 32 KB of LDS lets five workgroups share a CU, and these grids are latency chains, not MFMA-bound.
     // gemm_variant 5 / 6 force the earlier 128 x 128 shallow / 128 x 64 deep forms, 9 this one (A/B runs).

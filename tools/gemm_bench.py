@@ -28,7 +28,7 @@ TEXT_SHAPES = [(f"{nm} M={M}", M, N, K, e) for M in (99, 6336, 19000)
 
 
 # the reference's own training batch (B 4: M = 4 x 201 = 804 rows) and the 50-class text tower beside it (50 prompts x ~20 positions)
-SMALL_SHAPES = [(f"{nm} M={M}", M, N, K, e) for M, w in ((804, 768), (1000, 512))
+SMALL_SHAPES = [(f"{nm} M={M}", M, N, K, e) for M, w in ((804, 768), (1000, 512), (15000, 768), (9000, 768), (4000, 768))
                 for nm, N, K, e in (("qkv", 3 * w, w, 0), ("out", w, w, 5), ("fc", 4 * w, w, 1), ("proj", w, 4 * w, 5), ("dgelu", 4 * w, w, 3), ("dfc", w, 4 * w, 0), ("dqkv", w, 3 * w, 0))]
 
 
