@@ -220,6 +220,7 @@ int mudpt_layernorm_bwd(int32_t dtype, const void* dy, int32_t lddy, int32_t dy_
                         const float* dres, int32_t lddres, float* dx, int32_t lddx, void* dx_lp, int32_t lddx_lp,
                         int32_t rows, int32_t d, void* stream);
 int mudpt_attention_padded_len(int32_t L);
+/* causal: bit 0 = causal mask; bit 1 (tests / A-B, 224 < L <= 640 only) = the staged 16-query-block kernel instead of the resident one. */
 int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H,
                         int32_t causal, void* stream);
 /* The exact mode's forward (MUDPT_F32): q | k | v in fp32 [B, L, 3*H*64] -> the output as an fp16 [hi | lo] pair (out_lo may be NULL; row
@@ -228,7 +229,8 @@ int mudpt_attention_fwd_exact(const float* qkv32, void* qkv_lp, void* out_hi, vo
                               int32_t H, int32_t causal, void* stream);
 /* causal: bit 0 = causal mask.  Kernel choice (tests / A-B).  Default: padded length <= 96 (the text tower): the fused two-sweep pass over
  * resident Q, K, V, dO; longer non-causal sequences up to 224 (the vision tower): the single-sweep kernel (S, dP, exp computed once, dS
- * crosses LDS for dQ); otherwise the dQ kernel + dK/dV kernel pair (delta through `delta`).  bit 1 = force the two kernels, bit 3 = force the
+ * crosses LDS for dQ); otherwise a dQ kernel + dK/dV kernel pair (delta through `delta`): for L > 224 the resident pair while both operands of a
+ * (sequence, head) fit LDS (L <= 608), else (and for the window form, and with bit 1) the staged pair.  bit 1 = force the (staged) two kernels, bit 3 = force the
  * fused two-sweep pass, bit 2 = the same with two 16-row blocks per wave, bit 4 = force the single sweep (non-causal, L <= 224).
  * Window form (block 0 of a tower needs its input gradient on the prompt rows only): bits 20-27 = n > 0 wanted rows per sequence starting
  * at row bits 8-19.  The 16-row blocks (L > 224: 128-row groups) holding a wanted row are computed exactly as without the window; all other

@@ -894,8 +894,10 @@ __global__ __launch_bounds__(NC * 128) void attn_bwd_sweep_kernel(AttnArgs p, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Long sequences (L > 224: ViT-L/14@336 has 577 + n_ctx vision tokens, BASELINE configs[4]): the other operand no longer
-// fits in LDS next to everything else, so it streams through 64-row stages and the forward keeps a running (online) softmax.  Same
+// Long sequences (L > 224: ViT-L/14@336 has 577 + n_ctx vision tokens, BASELINE configs[4]), STAGED form: the other operand
+// streams through 64-row stages and the forward keeps a running (online) softmax.  Since the second half of round 3 the default up to
+// L = 608 / 640 (backward / forward) is the RESIDENT form of attention_resident.hip, where a pair's streamed operands do fit LDS whole;
+// these kernels serve longer sequences, the window and single-row forms and A/B runs (flag bit 1).  Same
 // fragment conventions and inner products as the whole-sequence kernels above.  One workgroup = 8 waves = 128 rows of the "lane"
 // operand (round 3; 4 waves / 64 rows before: every stage of the streamed operand now feeds twice the MFMAs).  The stages are double
 // buffered: the global loads of stage st + 1 are issued before stage st is computed and written to the other LDS buffer after it
