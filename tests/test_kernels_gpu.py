@@ -386,6 +386,8 @@ ATTN_CASES = [(3, 201, 12, False), (11, 77, 8, True), (2, 7, 3, False), (2, 33, 
               # (forward: K and V of a pair resident in LDS up to L = 640, one workgroup per pair; above that the staged 16-query-block form)
               (2, 300, 2, False), (1, 581, 3, False), (2, 260, 2, True), (1, 225, 1, False), (1, 640, 2, False), (1, 641, 1, False),
               (2, 513, 2, True), (70, 300, 4, False),
+              # backward: Q | dO | lse | delta of a pair resident up to L = 608; 609 .. 640: resident forward, staged backward
+              (1, 608, 1, False), (1, 609, 1, True),
               # more (sequence, head) pairs than resident workgroups: the persistent loops of the forward and the fused backward walk
               # several pairs per workgroup (images of the next pair stream in while the current one is computed)
               (150, 201, 2, False), (700, 20, 8, True)]
