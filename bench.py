@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--class-parallel", action="store_true", help="N > 1: each rank encodes C / N class prompts (two extra [C, embed] sums per step); "
                     "meant for --classes 1000 (BASELINE configs[2])")
     ap.add_argument("--no-split-k", action="store_true", help="never split the contraction of the small-grid GEMMs (A/B at small batches)")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE", help="any mudpt_model_set knob (include/mudpt.h), e.g. --knob defer_reduce=0 (A/B runs)")
     ap.add_argument("--no-attn-window", action="store_true", help="block 0's attention backward on all rows (A/B of the prompt-row window form)")
     ap.add_argument("--txt-buckets", type=int, default=0, help="maximum number of length buckets of the class prompts (0 = library default 3; 1 = none)")
     ap.add_argument("--fp32-streams", action="store_true", help="keep the gradient stream (and in bf16 mode the update stream) in fp32 (A/B of the T streams)")
@@ -210,6 +211,8 @@ def main():
     knobs = {}
     if args.gemm_variant:
         knobs["gemm_variant"] = args.gemm_variant
+    for kv in args.knob:
+        knobs[kv.split("=")[0]] = int(kv.split("=")[1])
     if args.fp32_streams:
         knobs["lp_grad"] = 0
     if args.attn_two_kernels:
