@@ -8,7 +8,6 @@ import math
 import pytest
 import torch
 
-from oracle import mudpt_oracle as O
 from tests.helpers import GoldenCase
 from tests.test_model_gpu import build
 
@@ -76,14 +75,16 @@ def test_logits_at_scale_100_within_1e_3(name):
     torch.cuda.synchronize()
     assert torch.equal(lg.cpu(), logits)  # the training step's forward is the inference forward
     assert abs(loss.item() - case.loss) <= slack * LOGIT_ATOL_EXACT
-    _, _, ref = O.forward_backward(case.cfg, case.frozen, case.params, case.class_embedding, case.eot, case.images, case.labels)
+    # gradients against the REFERENCE's own (the fixture: every tensor in full, the three big projection weights as the [::8, ::8] sample
+    # gen_golden.py stores; the oracle is held to the same fixtures on the CPU, tests/test_oracle_golden.py)
     for k, g in m.grads().items():
-        r = ref[k]
+        full, sample = case.grad(k), case.grad_sample(k)
+        r, g = (full, g.detach().cpu()) if full is not None else (sample, g.detach().cpu()[::8, ::8])
         rms_g = r.pow(2).mean().sqrt().item()
-        e = (g.detach().cpu() - r).abs().max().item()
+        e = (g - r).abs().max().item()
         print(f"  {k}: rms {rms_g:.3e} max err {e:.3e}")
         assert math.isfinite(e) and e <= GRAD_RTOL * rms_g * 4 + 1e-9, (k, e, rms_g)
-        assert torch.nn.functional.cosine_similarity(g.detach().cpu().flatten(), r.flatten(), dim=0).item() > 0.9995, k
+        assert torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item() > 0.9995, k
     m.close()
     # for the record: the fast modes at this scale (fp16 = split text tower only; bf16 = the benchmark mode) -- sanity-bounded only
     for dtype, bound in (("fp16", 1.2e-2), ("bf16", 0.25)):
