@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: MuDPT ViT-B/16 forward+backward(+SGD step) images/s, batch 256 per MI355X, bf16.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python bench.py --gpus N --steps K --warmup W          # N > 1 with WORLD_SIZE unset: starts N fresh child processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -84,18 +84,34 @@ def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start N fresh child processes of this same command line, one per
     GPU -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1 -- and wait for them.  This parent has
     not touched the GPU (no HIP call, no torch.cuda.is_available()) and never replaces itself: the children are ordinary subprocesses.
-    Rank 0's stdout (the ONE JSON line) is this process's stdout.  Replaces nn.DataParallel's single-process fan-out
-    (trainers/mudpt.py:230-233) at the bench level."""
+    Rank 0's stdout (the ONE JSON line) is this process's stdout; every rank's stderr is passed on line by line behind a "[rank r]" prefix.
+    Replaces nn.DataParallel's single-process fan-out (trainers/mudpt.py:230-233) at the bench level.
+
+    The job has a DEADLINE (MUDPT_BENCH_DEADLINE_S, default 480 s): a rank that hangs in the rendezvous or in a collective is not a dead
+    rank, so nothing else would ever end the job -- after the deadline the parent terminates the children it started (exact PIDs), says on
+    stderr which ranks were still running and for how long, and exits 124."""
     import socket
     import subprocess
+    import threading
+    deadline_s = float(os.environ.get("MUDPT_BENCH_DEADLINE_S", "480"))
     with socket.socket() as sk:  # a free rendezvous port
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, pumps = [], []
+
+    def pump(r, pipe):  # rank-prefixed stderr, line by line: what a hung or failing rank said last is on the parent's stderr
+        for line in iter(pipe.readline, b""):
+            sys.stderr.write(f"[rank {r}] " + line.decode(errors="replace"))
+            sys.stderr.flush()
+        pipe.close()
+
+    t_start = time.monotonic()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE))
+        pumps.append(threading.Thread(target=pump, args=(r, procs[r].stderr), daemon=True))
+        pumps[-1].start()
     rc = 0
     try:
         pending = set(range(n))
@@ -107,14 +123,33 @@ def launch_ranks(n: int) -> int:
                 pending.discard(r)
                 if code != 0 and rc == 0:
                     rc = code
+                    sys.stderr.write(f"bench.py: rank {r} exited with code {code} after {time.monotonic() - t_start:.0f} s; ending ranks {sorted(pending)}\n")
                     for q in pending:  # a dead rank leaves its peers in a collective: end them (exact PIDs we started)
                         procs[q].terminate()
+            if pending and time.monotonic() - t_start > deadline_s:
+                sys.stderr.write(f"bench.py: deadline of {deadline_s:.0f} s passed with ranks {sorted(pending)} of {n} still running "
+                                 f"(hung in the rendezvous or a collective?); terminating them\n")
+                for q in pending:
+                    procs[q].terminate()
+                t_kill = time.monotonic() + 10
+                while any(procs[q].poll() is None for q in pending) and time.monotonic() < t_kill:
+                    time.sleep(0.05)
+                rc = 124
+                break
             time.sleep(0.05)
     finally:
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
+        for th in pumps:
+            th.join(timeout=2)
     return rc
+
+
+def rendezvous_timeout():
+    """Timeout of init_process_group and of every collective of the bench (MUDPT_DIST_TIMEOUT_S, default 120 s)."""
+    from datetime import timedelta
+    return timedelta(seconds=float(os.environ.get("MUDPT_DIST_TIMEOUT_S", "120")))
 
 
 def stub_worker(args, rank: int, world: int):
@@ -124,8 +159,11 @@ def stub_worker(args, rank: int, world: int):
     import torch.distributed as dist
     if os.environ.get("MUDPT_BENCH_STUB_FAIL_RANK") == str(rank):
         raise SystemExit(3)  # test hook: a rank that dies before the rendezvous
+    if os.environ.get("MUDPT_BENCH_STUB_HANG_RANK") == str(rank):
+        print("stub rank: sleeping past the deadline", file=sys.stderr, flush=True)
+        time.sleep(3600)  # test hook: a rank that hangs (alive, never reaches the rendezvous)
     if world > 1:
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=rendezvous_timeout())
     bucket = torch.full((1243136,), float(rank + 1))
 
     def fence():
@@ -160,8 +198,8 @@ def stub_worker(args, rank: int, world: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)   # 10 warm-up, >= 50 timed steps, the median next to the mean
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--classes", type=int, default=11)
     ap.add_argument("--arch", default="vit_b16", choices=["vit_b16", "vit_l14_336"], help="vit_l14_336 = BASELINE configs[4] (not the headline line)")
@@ -204,7 +242,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(os.environ.get("MUDPT_BENCH_BACKEND", "nccl"))  # "nccl" is RCCL over xGMI on ROCm
+        # "nccl" is RCCL over xGMI on ROCm.  A bounded rendezvous / collective timeout: the default (10 min) is the driver's whole bench limit
+        dist.init_process_group(os.environ.get("MUDPT_BENCH_BACKEND", "nccl"), timeout=rendezvous_timeout())
 
     from mudpt_amd.model import CustomCLIP, ModelShape
     from mudpt_amd import synth, capi, parallel
@@ -272,11 +311,18 @@ def main():
     if not args.no_profile:
         model.set_knob("prof_stride", stride)
         model.profile(True)
+    # one marker event per step on the stream the steps run on (the library launches on torch's current stream): per-step GPU times for
+    # the median; `value` stays the wall clock of the whole window over K steps, as the contract says
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         loss = step()
+    marks[args.steps].record()
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2]
     classes, exec_flop = model.profile_read_classes() if not args.no_profile else ({}, 0.0)
     gemm_ms, gemm_flop, gemm_n = classes.get("gemm_pp", (0.0, 0.0, 0))  # of the SAMPLED launches (every stride-th)
     model.profile(False)
@@ -343,7 +389,8 @@ def main():
         step_flop = flops_per_step(shape, B, C)
         out = {
             "metric": "images/sec fwd+bwd ViT-B/16 MuDPT" if args.arch == "vit_b16" else "images/sec fwd+bwd ViT-L/14@336 MuDPT", "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "ms_per_step_median": round(median_ms, 3),
+            "ms_per_step_min": round(step_ms[0], 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"MuDPT {'ViT-B/16' if args.arch == 'vit_b16' else 'ViT-L/14@336'} fwd+bwd+SGD, batch {B}/GPU, {C} class prompts, n_ctx {shape.n_ctx}, depth {shape.depth}, "
                                    f"synthetic {shape.image_size}x{shape.image_size} N(0,1) images, random-init frozen CLIP (BASELINE configs[{1 if args.arch == 'vit_b16' else 4}])",

@@ -105,6 +105,10 @@ int mudpt_forward(mudpt_model* m, const float* images_dev, int32_t batch, float*
 /* Same with flags.  MUDPT_FWD_REUSE_TEXT: keep the text features of the previous call (valid while the bound parameters
  * are unchanged): the reference recomputes the text tower for every test batch (trainers/mudpt.py:170-184). */
 #define MUDPT_FWD_REUSE_TEXT 1
+/* mudpt_cp_forward only: this forward is the first phase of a TRAINING step (mudpt_forward_backward implies it).  A training forward may
+ * split the contraction of the vision tower's out_proj / c_proj at tiny batches (<= 8 ViT-B images; a differently associated fp32 sum);
+ * an inference forward never does, so the logits of an image do not depend on the size of the test batch it arrives in. */
+#define MUDPT_FWD_TRAINING 2
 int mudpt_forward_ex(mudpt_model* m, const float* images_dev, int32_t batch, float* logits_dev, int32_t flags, void* stream);
 
 /* One training step's forward + backward: loss_dev[0] = mean cross-entropy over the batch, gradients of

@@ -117,6 +117,7 @@ def check(rc: int, what: str = ""):
 
 
 CP_VISION, CP_TEXT = 1, 2  # mudpt_cp_backward parts
+FWD_REUSE_TEXT, FWD_TRAINING = 1, 2  # mudpt_forward_ex / mudpt_cp_forward flags
 
 
 class _DeviceMemory:

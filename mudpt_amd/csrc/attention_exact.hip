@@ -48,6 +48,10 @@ __global__ __launch_bounds__(XW * 64) void attn_fwd_exact_kernel(AttnArgs p, int
 
     const int q0 = qc * XQ + w * 16, qrow = q0 + n;
     const bool qvalid = qrow < L;
+    // the padded tail [L, Lp) of the log-sum-exp row reads as 0, like the fp16 forward kernels leave it: the whole-pair backward kernels
+    // load those rows unguarded (their dQ is never stored, but the invariant "no uninitialised value enters the arithmetic" holds).
+    // Lp <= nchunks * XQ (XQ is a multiple of 32), so every padded row belongs to some wave of the grid, live or not.
+    if (g == 0 && p.lse && !qvalid && qrow < Lp) p.lse[((size_t)b * p.H + h) * Lp + qrow] = 0.f;
     // Q fragment: Q[qrow][16 g + s]
     float qf[16];
     {

@@ -194,7 +194,9 @@ struct mudpt_model {
     int txt_buckets = 3;   // knob: at most this many length buckets for the class prompts (1 = every prompt runs to the longest EOT)
     bool attn_fused_w1 = false;
     bool split_k = true;      // knob: split K for the small-grid, long-K store GEMMs (small batches)
-    bool fwd_split_k = true;  // knob: ... of the forward too, up to kFwdSplitTiles tiles (gemm_call)
+    bool fwd_split_k = true;  // knob: ... of the forward too, up to kFwdSplitTiles tiles (gemm_call) -- in a TRAINING step's forward only
+    bool train_fwd = false;   // the forward in flight belongs to a training step (mudpt_forward_backward, mudpt_cp_forward with MUDPT_FWD_TRAINING):
+                              // inference forwards never split K, so eval logits of an image do not depend on the size of its (last, partial) test batch
     static constexpr size_t kFwdSplitTiles = 320;
     static constexpr size_t kScratchElems = (size_t)4 << 20;  // 4 slices x 128 tiles of 128 x 64 fp32
     float *gemm_scratch = nullptr, *gemm_scratch2 = nullptr;
@@ -255,7 +257,7 @@ static int gemm_call(mudpt_model* m, int epi, const GemmArgs& a, hipStream_t s, 
     // tower's small GEMMs run on the side stream, where an event pair would mostly measure queueing behind the other stream.
     GemmOpts o;
     o.variant = m->gemm_variant;
-    const bool fwd_small = fwd_split && m->fwd_split_k && (size_t)((a.M + 63) / 64) * ((a.N + 63) / 64) <= mudpt_model::kFwdSplitTiles;
+    const bool fwd_small = fwd_split && m->fwd_split_k && m->train_fwd && (size_t)((a.M + 63) / 64) * ((a.N + 63) / 64) <= mudpt_model::kFwdSplitTiles;
     if (m->split_k && (bwd || fwd_small)) {  // split-K partials: one scratch per stream (the towers run concurrently)
         o.scratch = s == m->s2 ? m->gemm_scratch2 : m->gemm_scratch;
         o.scratch_elems = mudpt_model::kScratchElems;
@@ -1283,6 +1285,7 @@ extern "C" int mudpt_forward_ex(mudpt_model* m, const float* images, int32_t B, 
     hipStream_t s = (hipStream_t)stream;
     const bool reuse = (flags & MUDPT_FWD_REUSE_TEXT) != 0 && !m->cocoop;  // CoCoOp's text features depend on the image
     if (reuse && !m->text_valid) { set_error("forward: MUDPT_FWD_REUSE_TEXT before any text-tower pass"); return MUDPT_ERR_STATE; }
+    m->train_fwd = false;
     TRY(forward_impl(m, images, B, s, reuse));
     HIP_TRY(hipMemcpyAsync(logits, m->logits, (size_t)B * m->cfg.n_cls * 4, hipMemcpyDeviceToDevice, s));
     return MUDPT_OK;
@@ -1415,6 +1418,7 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     TRY(ready(m, B, true));
     ARG_CHECK(images && labels && loss, "forward_backward: null argument");
     hipStream_t s = (hipStream_t)stream;
+    m->train_fwd = true;
     if (m->cocoop) return cocoop_forward_backward(m, images, labels, B, grad_scale, loss, logits, s);
     TRY(not_sharded(m, "forward_backward"));
     TRY(towers_forward(m, images, B, s, false));
@@ -1461,6 +1465,7 @@ extern "C" int mudpt_cp_forward(mudpt_model* m, const float* images, int32_t B, 
     ARG_CHECK(images && !m->cocoop, "cp_forward: null images / not a MuDPT model");
     const bool reuse = (flags & MUDPT_FWD_REUSE_TEXT) != 0;
     if (reuse && !m->text_valid) { set_error("cp_forward: MUDPT_FWD_REUSE_TEXT before any text-tower pass"); return MUDPT_ERR_STATE; }
+    m->train_fwd = (flags & MUDPT_FWD_TRAINING) != 0;
     TRY(towers_forward(m, images, B, (hipStream_t)stream, reuse));
     m->cp_B = B; m->cp_stage = 1;
     return MUDPT_OK;

@@ -231,7 +231,7 @@ class CustomCLIP(nn.Module):
         label = label.to(self.device, torch.int64).contiguous()
         B = image.shape[0]
         logits = torch.empty(B, self.n_cls, dtype=torch.float32, device=self.device) if return_logits else None
-        capi.check(self.lib.mudpt_cp_forward(self._h, capi.ptr(image), B, 0, self._stream()), "cp_forward")
+        capi.check(self.lib.mudpt_cp_forward(self._h, capi.ptr(image), B, capi.FWD_TRAINING, self._stream()), "cp_forward")
         self._exchange(self._cp_feat)
         capi.check(self.lib.mudpt_cp_head(self._h, capi.ptr(label), B, grad_scale, capi.ptr(self._loss), capi.ptr(logits), 0, self._stream()), "cp_head")
         work = self._exchange(self._cp_dfeat, async_op=True)

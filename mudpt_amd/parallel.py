@@ -30,7 +30,11 @@ def init(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if torch.cuda.is_available():
             torch.cuda.set_device(local)  # RCCL binds the communicator to the current device
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+        # a bounded rendezvous / collective timeout (MUDPT_DIST_TIMEOUT_S, default 600 s as torch's own): a rank that never arrives fails the
+        # job with an error instead of holding the others for torch's default on every later collective as well
+        from datetime import timedelta
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"),
+                                timeout=timedelta(seconds=float(os.environ.get("MUDPT_DIST_TIMEOUT_S", "600"))))
     return rank, world, local
 
 
@@ -117,16 +121,36 @@ class ShardedBatchSampler:
     global batch sampler (equal seeds: Dassl seeds torch / numpy / random from cfg.SEED on every rank), so the slices of a step are
     disjoint and their concatenation over the ranks is exactly the single-process batch, in the single-process order: what
     nn.DataParallel's scatter of ONE loaded batch gives (trainers/mudpt.py:230-233) -- but each rank only reads and decodes its own
-    images."""
+    images.
 
-    def __init__(self, batch_sampler, rank: int, world: int):
-        self.batch_sampler, self.rank, self.world = batch_sampler, rank, world
+    That only holds while every rank's sampler draws the same permutation, i.e. while the ranks' RNG streams stay in lock-step; a rank
+    that consumed one extra random number would silently train on overlapping / missing samples.  ``check_group`` (a gloo group made by
+    ``shard_loader``; its collectives are independent of the gradient all-reduce's, so the loader's prefetch thread may issue them)
+    verifies it once per epoch: a checksum of the epoch's FIRST global index batch must agree on all ranks, else every rank raises."""
+
+    def __init__(self, batch_sampler, rank: int, world: int, check_group=None):
+        self.batch_sampler, self.rank, self.world, self.check_group = batch_sampler, rank, world, check_group
+
+    def _check_lock_step(self, idx):
+        import zlib
+        import torch.distributed as dist
+        h = float(zlib.crc32(torch.tensor(idx, dtype=torch.int64).numpy().tobytes()))  # < 2^32: exact in float64
+        t = torch.tensor([h, -h], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.check_group)
+        if t[0].item() != -t[1].item():  # max(h) != min(h): some rank drew a different batch -- detected on EVERY rank
+            raise RuntimeError("data-parallel ranks drew different global index batches (rank %d: first indices %s): the ranks' RNG streams are out of "
+                               "lock-step, so their shards would overlap / miss samples.  Seed every rank identically before the loader is built, or use a "
+                               "rank-aware sampler with MUDPT_DATA_SHARDED=1" % (self.rank, idx[:8]))
 
     def __iter__(self):
+        first = True
         for idx in self.batch_sampler:
             idx = list(idx)
             if len(idx) % self.world != 0:
                 raise ValueError(f"global batch {len(idx)} is not divisible by the {self.world} data-parallel ranks")
+            if first and self.check_group is not None:
+                self._check_lock_step(idx)
+            first = False
             r = shard(len(idx), self.rank, self.world)
             yield idx[r.start:r.stop]
 
@@ -134,14 +158,25 @@ class ShardedBatchSampler:
         return len(self.batch_sampler)
 
 
+def loader_is_rank_aware(loader) -> bool:
+    """The documented opt-out (MUDPT_DATA_SHARDED=1), or a loader built on torch's DistributedSampler: its batches are per-rank already."""
+    if os.environ.get("MUDPT_DATA_SHARDED") == "1":
+        return True
+    from torch.utils.data.distributed import DistributedSampler
+    bs = getattr(loader, "batch_sampler", None)
+    return isinstance(getattr(loader, "sampler", None), DistributedSampler) or isinstance(getattr(bs, "sampler", None), DistributedSampler)
+
+
 def shard_loader(loader, r: int | None = None, world: int | None = None):
     """A rank-aware copy of a torch DataLoader (same dataset, workers, collate function; batch sampler wrapped in
     ShardedBatchSampler), or None when ``loader`` is not a DataLoader with a batch sampler (list-like synthetic loaders, iterable
-    datasets): the caller then falls back to slicing the loaded global batch (``shard_batch``)."""
+    datasets): the caller then falls back to slicing the loaded global batch (``shard_batch``).  A loader that is rank-aware already
+    (``loader_is_rank_aware``) is returned unchanged: sharding it again would keep 1/world of every per-rank batch."""
     from torch.utils.data import DataLoader
+    import torch.distributed as dist
     r = rank() if r is None else r
     world = world_size() if world is None else world
-    if world == 1:
+    if world == 1 or loader_is_rank_aware(loader):
         return loader
     if not isinstance(loader, DataLoader) or getattr(loader, "batch_sampler", None) is None:
         return None
@@ -149,7 +184,9 @@ def shard_loader(loader, r: int | None = None, world: int | None = None):
               worker_init_fn=loader.worker_init_fn, generator=loader.generator)
     if loader.num_workers > 0:
         kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=loader.persistent_workers)
-    return DataLoader(loader.dataset, batch_sampler=ShardedBatchSampler(loader.batch_sampler, r, world), **kw)
+    # the lock-step check's own group (every rank passes here: new_group is collective).  gloo on CPU tensors whatever the main backend is
+    group = dist.new_group(backend="gloo") if dist.is_available() and dist.is_initialized() and dist.get_world_size() == world else None
+    return DataLoader(loader.dataset, batch_sampler=ShardedBatchSampler(loader.batch_sampler, r, world, group), **kw)
 
 
 def barrier():
@@ -158,14 +195,14 @@ def barrier():
         dist.barrier()
 
 
-def all_finite(loss: torch.Tensor, flat_grads: torch.Tensor) -> bool:
-    """Consensus form of Dassl's non-finite-loss check (``detect_anomaly``): a rank that raised alone would leave the others
-    hanging in the next collective, so the flag is reduced (MIN) and every rank takes the same branch."""
-    ok = (torch.isfinite(loss).all() & torch.isfinite(flat_grads).all()).to(torch.float32).reshape(1)
+def all_ok(ok: bool) -> bool:
+    """True iff ``ok`` on every rank (one MIN all-reduce): lets all ranks take the same branch after a step only one of them can fail."""
     if world_size() > 1:
         import torch.distributed as dist
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    return bool(ok.item() > 0)
+        t = torch.tensor([1.0 if ok else 0.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item() > 0)
+    return ok
 
 
 def shard(n_items: int, rank: int, world: int) -> range:

@@ -118,7 +118,7 @@ def install_loader(trainer, local: int):
     if loader is None or isinstance(loader, DevicePrefetcher):
         return
     if parallel.world_size() > 1:
-        sharded = parallel.shard_loader(loader)
+        sharded = parallel.shard_loader(loader)  # unchanged if the loader is rank-aware already (MUDPT_DATA_SHARDED=1, DistributedSampler)
         if sharded is not None:
             loader, trainer._loader_sharded = sharded, True
     trainer.train_loader_x = DevicePrefetcher(loader, device=f"cuda:{local}", shard=not trainer._loader_sharded)
@@ -137,12 +137,19 @@ def parse_batch(trainer, batch):
 
 def save_on_main(trainer, save, *args, **kwargs):
     """Replicas are identical: rank 0 alone writes OUTPUT_DIR; the others wait until the file is complete, so that a load_model that
-    follows (Dassl's after_train with TEST.FINAL_MODEL = best_val, a resume) never reads a missing or half-written checkpoint."""
-    try:
-        if parallel.is_main():
+    follows (Dassl's after_train with TEST.FINAL_MODEL = best_val, a resume) never reads a missing or half-written checkpoint.  The wait
+    is an exchange of rank 0's success flag, not a bare barrier: if the save raised, EVERY rank raises (the others would otherwise walk
+    on into the next collective, or into reading the missing file, while rank 0 unwinds)."""
+    err = None
+    if parallel.is_main():
+        try:
             save(*args, **kwargs)
-    finally:
-        parallel.barrier()
+        except Exception as e:  # noqa: BLE001 -- re-raised below, after the other ranks have been told
+            err = e
+    if not parallel.all_ok(err is None):
+        if err is not None:
+            raise err
+        raise RuntimeError("rank 0 failed to write the checkpoint (its traceback is on rank 0's stderr)")
 
 
 def load_plugin_checkpoint(trainer, directory, epoch, drop_keys, skipped_note):

@@ -51,6 +51,32 @@ def test_a_failing_rank_ends_the_job():
     assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
 
 
+def test_a_hanging_rank_hits_the_deadline():
+    """A rank that is alive but never reaches the rendezvous (or sits in a collective) is not a dead rank: the parent's own deadline
+    (MUDPT_BENCH_DEADLINE_S) terminates the children it started, names the ranks still running on stderr and exits 124; the ranks' own
+    stderr arrives rank-prefixed.  The other rank's rendezvous timeout is longer than the deadline here, so the deadline is what fires."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MUDPT_BENCH_STUB="1", MUDPT_BENCH_STUB_HANG_RANK="1", MUDPT_BENCH_DEADLINE_S="6", MUDPT_DIST_TIMEOUT_S="300")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 124, (r.returncode, r.stdout, r.stderr)
+    assert time.time() - t0 < 60
+    assert "deadline of 6 s passed" in r.stderr and "still running" in r.stderr
+    assert "[rank 1] stub rank: sleeping past the deadline" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # no JSON line: the job did not finish
+
+
+def test_a_rendezvous_timeout_ends_a_rank_on_its_own():
+    """init_process_group carries a bounded timeout (MUDPT_DIST_TIMEOUT_S, default 120 s; torch's default is 10 min = the driver's whole
+    bench limit): the rank that waits for a peer that never arrives fails by itself, and that failure ends the job."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MUDPT_BENCH_STUB="1", MUDPT_BENCH_STUB_HANG_RANK="1", MUDPT_BENCH_DEADLINE_S="100", MUDPT_DIST_TIMEOUT_S="4")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode not in (0, 124), (r.returncode, r.stderr)
+    assert "[rank 0]" in r.stderr and "rank 0 exited with code" in r.stderr
+
+
 def test_every_tracked_workload_has_its_traffic_profile():
     """bench.py's roofline.traffic comes from the rocprofv3 PMC passes committed under profiles/ for the SAME workload (tools/profile_round.sh);
     every workload it knows a tag for must have its file, with the dominant kernel's class in it."""

@@ -70,7 +70,7 @@ def test_two_sharded_handles_with_manual_exchange_match_reference_and_unsharded(
     img = [c.images[r * per:(r + 1) * per].cuda().contiguous() for r in range(world)]
     lab = [c.labels[r * per:(r + 1) * per].cuda().contiguous() for r in range(world)]
     for r, m in enumerate(ranks):
-        capi.check(lib.mudpt_cp_forward(m._h, capi.ptr(img[r]), per, 0, st), "cp_forward")
+        capi.check(lib.mudpt_cp_forward(m._h, capi.ptr(img[r]), per, capi.FWD_TRAINING, st), "cp_forward")
     torch.cuda.synchronize()
     # exchange 1: rows of the other rank are zero -> the sum is the gather
     for r, m in enumerate(ranks):
@@ -137,7 +137,7 @@ def test_text_tower_sharding_is_exact_given_the_same_tables(shards):
         m = CustomCLIP(shape_of(c.cfg), c.frozen, c.tokens, max_batch=B, dtype="fp16", class_shard=shard)
         m.set_params(c.params)
         st = m._stream()
-        capi.check(m.lib.mudpt_cp_forward(m._h, capi.ptr(img), B, 0, st), "cp_forward")
+        capi.check(m.lib.mudpt_cp_forward(m._h, capi.ptr(img), B, capi.FWD_TRAINING, st), "cp_forward")
         torch.cuda.synchronize()
         feat = m._cp_feat.clone()
         if table is not None:

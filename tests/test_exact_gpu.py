@@ -37,7 +37,7 @@ def test_exact_attention_forward(B, L, H, causal):
         qkv[0, L - 1, d:d + 64] *= 5.0
     Lp = lib.mudpt_attention_padded_len(L)
     hi = torch.zeros(B, L, 2 * d, device="cuda", dtype=torch.float16)  # [hi | lo] rows
-    lse = torch.zeros(B, H, Lp, device="cuda")
+    lse = torch.full((B, H, Lp), float("nan"), device="cuda")  # the kernel must write every row, the padded tail included
     lp = torch.zeros(B, L, 3 * d, device="cuda", dtype=torch.float16)
     rc = lib.mudpt_attention_fwd_exact(P(qkv), P(lp), P(hi), C.c_void_p(hi.data_ptr() + d * 2), 2 * d, P(lse), B, L, H, int(causal), None)
     assert rc == 0, lib.mudpt_last_error().decode()
@@ -54,6 +54,7 @@ def test_exact_attention_forward(B, L, H, causal):
     assert err <= 8e-6 * max(scale, 1.0)  # fp32 score rounding at |s| ~ 50 (torch fp32 on the CPU: 6e-6 on this input) + the [hi | lo] pair's 2^-22
     ref_lse = torch.logsumexp(s, dim=-1)
     assert (lse[:, :, :L].double().cpu() - ref_lse).abs().max().item() <= 2e-5
+    assert (lse[:, :, L:] == 0).all()  # the padded tail the whole-pair backward kernels read (as the fp16 forward kernels leave it)
     assert torch.equal(lp.cpu(), qkv.half().cpu())
     # hi is the fp16 rounding of the value, lo the remainder: |lo| <= half an ulp of hi
     ulp = torch.ldexp(torch.ones(()), torch.frexp(hi[..., :d].float().abs().clamp_min(6.2e-5)).exponent - 11).cpu()

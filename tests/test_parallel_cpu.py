@@ -107,9 +107,17 @@ def _plugin_worker(rank, world, port, out):
     t.device, t.batch_idx, t.num_batches = torch.device("cpu"), 0, 99
     losses = [t.forward_backward(b)["loss"] for b in batches]
     assert t.model.calls == [((B // world, 3, case.cfg.image_size, case.cfg.image_size), 1.0 / world)] * 2, t.model.calls
-    # a non-finite loss on ONE rank must stop every rank (no hang in the next collective)
+    # a non-finite loss on ONE rank must stop every rank (no hang in the next collective): the consensus of the step
     bad = torch.tensor(float("nan") if rank == 1 else 1.0)
-    assert parallel.all_finite(bad, t.model.flat_grads) is False
+    assert parallel.step_consensus(bad, t.model.flat_grads)[0] is False
+    # rank 0's checkpoint write fails: EVERY rank raises (no rank walks on into the next collective or a missing file)
+    def failing_save():
+        raise OSError("disk full")
+    with pytest.raises(OSError if rank == 0 else RuntimeError):
+        trainer.save_on_main(t, failing_save)
+    done = []
+    trainer.save_on_main(t, lambda: done.append(1))
+    assert done == ([1] if rank == 0 else [])
     torch.save({"params": t.model.flat_params.clone(), "losses": losses}, f"{out}.r{rank}")
     import torch.distributed as dist
     dist.barrier()
@@ -262,6 +270,56 @@ def test_rank_aware_loader_splits_every_global_batch(tmp_path):
     torch.testing.assert_close(torch.tensor(r0["losses"]), torch.tensor(losses), atol=2e-6, rtol=1e-5)
     assert torch.equal(r0["params"], r1["params"])
     torch.testing.assert_close(r0["params"], t.model.flat_params, atol=2e-6, rtol=1e-5)
+
+
+def _lockstep_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from mudpt_amd import parallel
+    import torch.distributed as dist
+    parallel.init("gloo")
+    ds = _ToyDataset(16, 4)
+    # (1) ranks in lock-step: two epochs pass the per-epoch check
+    ld = parallel.shard_loader(_toy_loader(ds, 4))
+    torch.manual_seed(99)
+    epochs = [[b["index"].tolist() for b in ld] for _ in range(2)]
+    # (2) rank 1 consumed ONE extra random number before the epoch's permutation is drawn: both ranks must raise, nobody hangs
+    torch.manual_seed(99)
+    if rank == 1:
+        torch.rand(1)
+    try:
+        list(ld)
+        raised = None
+    except RuntimeError as e:
+        raised = str(e)
+    # (3) a loader that is rank-aware already is left alone: the documented opt-out, and torch's DistributedSampler
+    from torch.utils.data.distributed import DistributedSampler
+    dl = torch.utils.data.DataLoader(ds, batch_size=2, sampler=DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=False))
+    same = parallel.shard_loader(dl) is dl
+    per_rank = [b["index"].tolist() for b in dl]
+    os.environ["MUDPT_DATA_SHARDED"] = "1"
+    plain = torch.utils.data.DataLoader(ds, batch_size=4)
+    opt_out = parallel.shard_loader(plain) is plain
+    del os.environ["MUDPT_DATA_SHARDED"]
+    torch.save({"epochs": epochs, "raised": raised, "same": same, "per_rank": per_rank, "opt_out": opt_out}, f"{out}.r{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_sampler_verifies_rank_lock_step_and_leaves_rank_aware_loaders_alone(tmp_path):
+    """ShardedBatchSampler is only right while every rank draws the same permutation.  Once per epoch a checksum of the first global index
+    batch is compared over the ranks (its own gloo group); a rank whose RNG stream slipped makes EVERY rank raise.  A loader that is
+    per-rank already (MUDPT_DATA_SHARDED=1, DistributedSampler) is returned unchanged, not sharded twice."""
+    out = str(tmp_path / "ls")
+    mp.spawn(_lockstep_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".r0"), torch.load(out + ".r1")
+    for e0, e1 in zip(r0["epochs"], r1["epochs"]):
+        assert len(e0) == 4 and all(len(a) == 2 and set(a).isdisjoint(b) for a, b in zip(e0, e1))
+        assert sorted(i for b in e0 + e1 for i in b) == list(range(16))
+    assert r0["raised"] and r1["raised"] and "lock-step" in r0["raised"] and "lock-step" in r1["raised"]
+    assert r0["same"] and r1["same"] and r0["opt_out"] and r1["opt_out"]
+    assert sorted(i for b in r0["per_rank"] + r1["per_rank"] for i in b) == list(range(16))  # each rank kept its WHOLE per-rank batches
 
 
 def test_shard_loader_falls_back_for_list_like_loaders():
