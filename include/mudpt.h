@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MUDPT_ABI_VERSION 5
+#define MUDPT_ABI_VERSION 6
 
 #define MUDPT_OK 0
 #define MUDPT_ERR_ARG 1   /* bad argument / shape (the reference raises AssertionError, mudpt.py:52,55,190) */
@@ -45,11 +45,18 @@ extern "C" {
 
 #define MUDPT_BF16 0
 #define MUDPT_F16 1
-/* "Exact" mode, what PREC = "fp32" selects (the reference's CPU path is fp32 whatever PREC says: clip/clip.py:142-143): fp16 MFMA
- * operands, but every forward GEMM operand is a [hi | lo] fp16 pair contracted against the (fp16-exact, as CLIP checkpoints store
- * them) weights -- 22 significant bits --, pixels included, and the attention forward runs in fp32 on the matrix cores
- * (v_mfma_f32_16x16x4_f32).  Meets north_star's 1e-3 logit bound at the logit scale pretrained checkpoints carry (100).  The backward
- * is the MUDPT_F16 one. */
+/* The PARITY mode, what PREC = "fp32" selects (the reference's CPU path is fp32 whatever PREC says: clip/clip.py:142-143): the mode that
+ * holds north_star's bound -- logits within 1e-3 of the reference -- at the logit scale pretrained checkpoints carry (exp(logit_scale) =
+ * 100, trainers/mudpt.py:181).  fp16 MFMA operands with SPLIT forward GEMM operands (hi = fp16(v) plus the remainder, contracted in a
+ * second pass against the fp16-exact weights, as CLIP checkpoints store them):
+ *   text tower    remainder as fp16 (22 bits) + attention forward in fp32 on the matrix cores (v_mfma_f32_16x16x4_f32): each of its
+ *                 rounding sites alone moves the logits by 2.5e-3;
+ *   vision tower  remainder as e4m3, contracted against an e4m3 copy of the weights on the MX-scaled fp8 matrix instruction
+ *                 (v_mfma_scale_f32_16x16x128_f8f6f4: twice the fp16 rate, so the second pass costs half of the first), pixels included;
+ *                 attention in fp16.
+ * Measured against the reference's own logits at scale 100: <= 3.5e-4 (ViT-B/16; 8e-5 ViT-L/14@336), 1.27x the bf16 step.  Knobs
+ * (mudpt_model_set): vis_exact_attn = 1 -> 8e-5; vis_lo = 1 + vis_exact_attn = 1 -> round 3's "exact" mode, 2.5e-5 at 1.56x.  The
+ * backward is the MUDPT_F16 one with fp16 activation gradients.  Per-site ablation: DESIGN.md 2. */
 #define MUDPT_F32 2
 
 #define MUDPT_VARIANT_MUDPT 0  /* trainers/mudpt.py: deep multi-modal prompts, 10 trainables */
@@ -63,7 +70,7 @@ typedef struct mudpt_config {
     int32_t n_ctx, depth; /* TRAINER.MUDPT.N_CTX / DEEP_PROMPT_DEPTH (train.py:115-119) */
     int32_t n_cls;        /* number of class prompts */
     int32_t max_batch;    /* activations are sized for this many images */
-    int32_t dtype;        /* MUDPT_BF16 / MUDPT_F16: MFMA operand type (fp32 accumulate, fp32 residual stream); MUDPT_F32: exact mode */
+    int32_t dtype;        /* MUDPT_BF16 / MUDPT_F16: MFMA operand type (fp32 accumulate, fp32 residual stream); MUDPT_F32: the parity mode */
     int32_t variant;      /* MUDPT_VARIANT_*; CoCoOp runs max_batch * n_cls text sequences per step */
 } mudpt_config;
 
@@ -212,10 +219,22 @@ int mudpt_gemm(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K,
                const void* B, int32_t ldb, const float* bias, void* out0, int32_t ldo0, void* out1, int32_t ldo1,
                const void* aux, int32_t ldaux, int32_t patches, int32_t seq_len, const float* pos, int32_t variant, void* stream);
 /* variant: kernel-choice knob for tests / tuning (0 = the default dispatch). */
-/* The c_fc GEMM of a split-operand tower (MUDPT_F32, and the text tower under MUDPT_F16): u = A . B^T + bias (T), QuickGELU(u) as the
- * [hi | lo] pair g_hi + g_lo (both T, row stride ldg) that the c_proj GEMM contracts against [W | W]. */
-int mudpt_gemm_gelu_split(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb, const float* bias,
-                          void* u, int32_t ldu, void* g_hi, void* g_lo, int32_t ldg, void* stream);
+/* A GEMM with a SPLIT A operand (the forward GEMMs of the parity mode): A = T(v), A_lo = the remainder v - A in a second buffer
+ * with the row stride of A in bytes.  lo_mode 1: A_lo holds T values and a second pass contracts it against the same B (22 bits); lo_mode 2:
+ * A_lo holds OCP e4m3 bytes of (v - A) * 2^12 (the first K bytes of each row) and the second pass runs on the MX-scaled fp8 matrix
+ * instruction against B8, the e4m3 copy of B ([N, K] bytes at the row stride of B in bytes, values B * 2^shift, b8_scale = 127 - shift =
+ * the E8M0 block scale); K % 128 == 0 and dtype fp16 then.  lo_mode 0: no second pass.  epilogue 0 | 1 | 2 | 5 as mudpt_gemm; with
+ * epilogue 1, out1_lo (may be NULL) receives the low half of out1 = QuickGELU(u) in form out1_lo_mode (1 / 2), at the row stride of out1 in bytes. */
+int mudpt_gemm_split(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, const void* A, const void* A_lo, int32_t lo_mode, int32_t lda,
+                     const void* B, const void* B8, int32_t b8_scale, int32_t ldb, const float* bias, void* out0, int32_t ldo0, void* out1,
+                     void* out1_lo, int32_t out1_lo_mode, int32_t ldo1, const void* aux, int32_t ldaux, int32_t variant, void* stream);
+/* HOST helper (no device work): out[i] = OCP e4m3 (round to nearest even, saturating at +-448) of in[i] * 2^shift -- the conversion the
+ * library applies to the frozen weights for the e4m3 second pass. */
+int mudpt_e4m3_from_f32(const float* in_host, uint8_t* out_host, size_t n, int32_t shift);
+/* LayerNorm forward writing a split operand: out = T(y), out_lo = the remainder in form lo_mode (1: T, 2: e4m3 bytes of (y - out) * 2^12),
+ * rows of ldo elements of T / 2 ldo bytes. */
+int mudpt_layernorm_fwd_split(int32_t dtype, const float* x, int32_t ldx, const float* gamma, const float* beta, void* out, void* out_lo,
+                              int32_t lo_mode, int32_t ldo, int32_t rows, int32_t d, void* stream);
 int mudpt_layernorm_fwd(int32_t dtype, const float* x, int32_t ldx, const int32_t* row_index, const float* gamma,
                         const float* beta, void* out, int32_t ldo, int32_t out_f32, float* mean, float* rstd,
                         int32_t rows, int32_t d, void* stream);
@@ -227,10 +246,11 @@ int mudpt_attention_padded_len(int32_t L);
 /* causal: bit 0 = causal mask; bit 1 (tests / A-B, 224 < L <= 640 only) = the staged 16-query-block kernel instead of the resident one. */
 int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, float* lse, int32_t B, int32_t L, int32_t H,
                         int32_t causal, void* stream);
-/* The exact mode's forward (MUDPT_F32): q | k | v in fp32 [B, L, 3*H*64] -> the output as an fp16 [hi | lo] pair (out_lo may be NULL; row
- * stride ld_out elements, 0 = H*64), lse, and -- if qkv_lp is not NULL -- the fp16 copy of q | k | v the backward kernels read. */
-int mudpt_attention_fwd_exact(const float* qkv32, void* qkv_lp, void* out_hi, void* out_lo, int32_t ld_out, float* lse, int32_t B, int32_t L,
-                              int32_t H, int32_t causal, void* stream);
+/* The fp32 attention forward (parity mode MUDPT_F32: the text tower, knob for the vision tower): q | k | v in fp32 [B, L, 3*H*64] -> the
+ * output as a split operand out_hi (fp16) + out_lo (may be NULL; form lo_mode 1 / 2 as in mudpt_gemm_split; row stride ld_out elements of
+ * fp16 = 2 ld_out bytes, 0 = H*64), lse, and -- if qkv_lp is not NULL -- the fp16 copy of q | k | v the backward kernels read. */
+int mudpt_attention_fwd_exact(const float* qkv32, void* qkv_lp, void* out_hi, void* out_lo, int32_t lo_mode, int32_t ld_out, float* lse, int32_t B,
+                              int32_t L, int32_t H, int32_t causal, void* stream);
 /* causal: bit 0 = causal mask.  Kernel choice (tests / A-B).  Default: padded length <= 96 (the text tower): the fused two-sweep pass over
  * resident Q, K, V, dO; longer non-causal sequences up to 224 (the vision tower): the single-sweep kernel (S, dP, exp computed once, dS
  * crosses LDS for dQ); otherwise a dQ kernel + dK/dV kernel pair (delta through `delta`): for L > 224 the resident pair while both operands of a

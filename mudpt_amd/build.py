@@ -31,6 +31,17 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel / host sources the library is built from: stamped into profiles/*_bytes_per_step.json by
+    tools/profile_round.sh, compared by bench.py -- a traffic figure measured on other kernels than the ones loaded is reported as null."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + ["common.h", "kernels.h"]):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)

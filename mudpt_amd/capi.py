@@ -11,7 +11,7 @@ HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "mudpt.h")
 
 BF16, F16, F32 = 0, 1, 2  # F32: the exact mode (include/mudpt.h MUDPT_F32)
 VARIANT_MUDPT, VARIANT_COCOOP = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD, EPI_PATCH, EPI_STORE_F32 = range(6)
 
 
@@ -60,13 +60,15 @@ SIGNATURES = {
     "mudpt_profile_read_classes": (_i32, [_vp, C.POINTER(C.c_double * 5), C.POINTER(C.c_double * 5), C.POINTER(C.c_int64 * 5), C.POINTER(C.c_double)]),
     "mudpt_gemm": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32,
                           _i32, _i32, _vp, _i32, _vp]),
-    "mudpt_gemm_gelu_split": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "mudpt_gemm_split": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "mudpt_e4m3_from_f32": (_i32, [_vp, _vp, _sz, _i32]),
+    "mudpt_layernorm_fwd_split": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mudpt_layernorm_fwd": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "mudpt_layernorm_bwd": (_i32, [_i32, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
                                    _i32, _i32, _i32, _vp]),
     "mudpt_attention_padded_len": (_i32, [_i32]),
     "mudpt_attention_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "mudpt_attention_fwd_exact": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mudpt_attention_fwd_exact": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mudpt_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mudpt_attention_fwd_single": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mudpt_attention_bwd_single": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -12,7 +12,7 @@ from __future__ import annotations
 from . import parallel, synth
 from .model import CustomCLIP, ModelShape
 from .trainer import (TRAINER_REGISTRY, TrainerX, build_lr_scheduler, build_optimizer, data_parallel_step, install_loader, load_clip_state_dict,
-                      load_plugin_checkpoint, load_pretrained_weights, parse_batch, precision_to_dtype, save_on_main, tokenize_prompts)
+                      load_plugin_checkpoint, load_pretrained_weights, parse_batch, precision_to_dtype, save_on_main, tokenize_prompts, warn_if_fp16_misses_the_bound)
 
 
 @TRAINER_REGISTRY.register()
@@ -39,6 +39,7 @@ class CoCoOp(TrainerX):
             shape = ModelShape.from_state_dict(state, n_ctx, 1)
         cfg_imsize = cfg.INPUT.SIZE[0]
         assert cfg_imsize == shape.image_size, f"cfg_imsize ({cfg_imsize}) must equal to clip_imsize ({shape.image_size})"  # :77
+        warn_if_fp16_misses_the_bound(cc.PREC, state)
         if ctx_init:
             ctx_ids = [int(v) for v in tokenize_prompts([ctx_init], shape.ctx_len, near=near)[0, 1:1 + n_ctx]] \
                 if ctx_init != "a photo of a" else synth.CTX_INIT_TOKENS[:n_ctx]

@@ -110,22 +110,29 @@ struct Attn {
         if (row < L) v = *(const vec8*)(src + (size_t)row * ld + ks * 32 + (lane >> 4) * 8);
         return v;
     }
-    // the same, plus the rounding remainder to a second row (the low half of a split operand)
-    __device__ static inline void store_t_split(elem* dst_row, elem* lo_row, const f32x4 (&x)[4], float scale, int lane) {
+    // the same, plus the rounding remainder to a second row (the low half of a split operand, common.h LoMode): lo_row points at the
+    // row's 64 columns of this head in the low buffer -- elements of T (LO_F16) or e4m3 bytes (LO_F8)
+    __device__ static inline void store_t_split(elem* dst_row, void* lo_row, int lo_mode, const f32x4 (&x)[4], float scale, int lane) {
         const int g = lane >> 4;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             vec4 v, l;
+            float rem[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                elem hv, lv;
-                split_hi_lo(x[dt][r] * scale, hv, lv);
+                elem hv;
+                rem[r] = split_rem(x[dt][r] * scale, hv);
                 v[r] = hv;
-                l[r] = lv;
+                l[r] = (elem)rem[r];
             }
             *(vec4*)(dst_row + 16 * dt + 4 * g) = v;
-            *(vec4*)(lo_row + 16 * dt + 4 * g) = l;
+            if (lo_mode == LO_F8) *(uint32_t*)((char*)lo_row + 16 * dt + 4 * g) = pack_lo8(rem[0], rem[1], rem[2], rem[3]);
+            else *(vec4*)((elem*)lo_row + 16 * dt + 4 * g) = l;
         }
+    }
+    // address of row `row`, head `hd` in the low buffer of a split output (same row stride in bytes as the T buffer: ldo elements of T)
+    __device__ static inline void* lo_ptr(void* base, int lo_mode, size_t row, size_t ldo, int hd) {
+        return lo_mode == LO_F8 ? (void*)((char*)base + row * ldo * 2 + hd * 64) : (void*)((elem*)base + row * ldo + hd * 64);
     }
     // D^T tile set (4 tiles of 16 d x 16 rows) -> dst[row][16 dt + 4 g + r]
     __device__ static inline void store_t(elem* dst_row, const f32x4 (&x)[4], float scale, int lane) {
@@ -212,7 +219,7 @@ __device__ inline void fwd_qblock(const AttnArgs& p, const typename T::elem* Ks,
     const size_t ldo = p.ld_out ? (size_t)p.ld_out : (size_t)HD;
     if (q < L) {
         const size_t off = ((size_t)b * L + q) * ldo + hd * 64;
-        if (p.out_lo) A::store_t_split((elem*)p.out + off, (elem*)p.out_lo + off, O, 1.f / l, lane);
+        if (p.out_lo) A::store_t_split((elem*)p.out + off, A::lo_ptr(p.out_lo, p.lo_mode, (size_t)b * L + q, ldo, hd), p.lo_mode, O, 1.f / l, lane);
         else A::store_t((elem*)p.out + off, O, 1.f / l, lane);
     }
     if (g == 0 && p.lse) p.lse[(size_t)pair * Lp + q] = q < L ? m * 0.125f + __logf(l) : 0.f;
@@ -999,7 +1006,7 @@ __global__ __launch_bounds__(TW * 64) void attn_fwd_tiled_kernel(AttnArgs p, int
     const size_t ldo = p.ld_out ? (size_t)p.ld_out : (size_t)HD;
     if (q < L) {
         const size_t off = ((size_t)b * L + q) * ldo + hd * 64;
-        if (p.out_lo) A::store_t_split((elem*)p.out + off, (elem*)p.out_lo + off, O, 1.f / l, lane);
+        if (p.out_lo) A::store_t_split((elem*)p.out + off, A::lo_ptr(p.out_lo, p.lo_mode, (size_t)b * L + q, ldo, hd), p.lo_mode, O, 1.f / l, lane);
         else A::store_t((elem*)p.out + off, O, 1.f / l, lane);
     }
     if (g == 0 && p.lse && q < Lp) p.lse[(size_t)pair * Lp + q] = q < L ? m * 0.125f + __logf(l) : 0.f;

@@ -25,6 +25,7 @@ namespace mudpt {
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4e;
 constexpr int XKT = 32;  // keys per staged tile
 constexpr int XW = 8, XQ = XW * 16;  // waves / queries per workgroup (round 3: 4 / 64 read K and V of a pair four times over: 1.4 GB per ViT-B/16 layer at B 256)
 
@@ -178,22 +179,30 @@ __global__ __launch_bounds__(XW * 64) void attn_fwd_exact_kernel(AttnArgs p, int
     if (g == 0 && p.lse) p.lse[((size_t)b * p.H + h) * Lp + qrow] = (m + __builtin_amdgcn_logf(lsum)) * 0.6931471805599453f;
     // o[dt][r] = O[qrow][16 g + 4 r + dt]
     f16x8 hi[2], lo[2];
+    float rem[16];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const int c = 4 * r + dt;
-            _Float16 hv, lv;
-            split_hi_lo(o[dt][r] * inv, hv, lv);
+            _Float16 hv;
+            rem[c] = split_rem(o[dt][r] * inv, hv);
             hi[c >> 3][c & 7] = hv;
-            lo[c >> 3][c & 7] = lv;
+            lo[c >> 3][c & 7] = (_Float16)rem[c];
         }
     const size_t off = ((size_t)b * L + qrow) * ld_out + h * 64 + 16 * g;
     f16x8* dh = (f16x8*)((_Float16*)p.out + off);
     dh[0] = hi[0]; dh[1] = hi[1];
-    if (p.out_lo) {
-        f16x8* dl = (f16x8*)((_Float16*)p.out_lo + off);
-        dl[0] = lo[0]; dl[1] = lo[1];
+    if (p.out_lo) {  // the low half of the split operand (common.h LoMode): fp16, or e4m3 bytes at the same row stride in bytes
+        if (p.lo_mode == LO_F8) {
+            u32x4e w;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[c] = pack_lo8(rem[4 * c], rem[4 * c + 1], rem[4 * c + 2], rem[4 * c + 3]);
+            *(u32x4e*)((char*)p.out_lo + ((size_t)b * L + qrow) * ld_out * 2 + h * 64 + 16 * g) = w;
+        } else {
+            f16x8* dl = (f16x8*)((_Float16*)p.out_lo + off);
+            dl[0] = lo[0]; dl[1] = lo[1];
+        }
     }
 }
 

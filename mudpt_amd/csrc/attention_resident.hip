@@ -177,14 +177,18 @@ __global__ __launch_bounds__(RES_W_MAX * 64) void attn_fwd_resident_kernel(AttnA
                 for (int rr = 0; rr < 4; ++rr) {
                     const int d0 = 32 * dt + 8 * rr + 4 * h;  // registers 4 rr .. 4 rr + 3 of tile dt are d0 .. d0 + 3 of this lane's query
                     vec4 hv, lv;
+                    float rem[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        elem a, c;
-                        split_hi_lo(O[dt][4 * rr + e] * inv, a, c);
-                        hv[e] = a; lv[e] = c;
+                        elem a;
+                        rem[e] = split_rem(O[dt][4 * rr + e] * inv, a);
+                        hv[e] = a; lv[e] = (elem)rem[e];
                     }
                     *(vec4*)((elem*)p.out + off + d0) = hv;
-                    if (p.out_lo) *(vec4*)((elem*)p.out_lo + off + d0) = lv;
+                    if (p.out_lo) {  // the low half of a split operand (common.h LoMode): T, or e4m3 bytes at the same row stride in bytes
+                        if (p.lo_mode == LO_F8) *(uint32_t*)((char*)p.out_lo + ((size_t)b * L + q) * ldo * 2 + hd * 64 + d0) = pack_lo8(rem[0], rem[1], rem[2], rem[3]);
+                        else *(vec4*)((elem*)p.out_lo + off + d0) = lv;
+                    }
                 }
         }
         if (h == 0 && p.lse && q < Lp) p.lse[(size_t)pair * Lp + q] = q < L ? m * 0.125f + __logf(l) : 0.f;

@@ -110,10 +110,19 @@ __global__ __launch_bounds__(256) void attn_fwd_single_kernel(AttnArgs p, const 
     if (rg == 0) {
         const size_t oo = (size_t)b * ld_out + hd * 64 + ch * 8;
         vec8 hi, lo;
+        float rem[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { elem hv, lv; split_hi_lo(o[j], hv, lv); hi[j] = hv; lo[j] = lv; }
+        for (int j = 0; j < 8; ++j) { elem hv; rem[j] = split_rem(o[j], hv); hi[j] = hv; lo[j] = (elem)rem[j]; }
         *(vec8*)((elem*)out_sel + oo) = hi;
-        if (out_lo) *(vec8*)((elem*)out_lo + oo) = lo;
+        if (out_lo) {  // the low half of a split operand (common.h LoMode)
+            if (p.lo_mode == LO_F8) {
+                uint32_t* d8 = (uint32_t*)((char*)out_lo + (size_t)b * ld_out * 2 + hd * 64 + ch * 8);
+                d8[0] = pack_lo8(rem[0], rem[1], rem[2], rem[3]);
+                d8[1] = pack_lo8(rem[4], rem[5], rem[6], rem[7]);
+            } else {
+                *(vec8*)((elem*)out_lo + oo) = lo;
+            }
+        }
     }
     if (lane == 0) lse_sel[pair] = m * 0.125f + __logf(l);
 }

@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // Operand dtype of the MFMA GEMMs / attention (fp32 accumulate, fp32 residual stream either way).
 enum DType : int { DT_BF16 = 0, DT_F16 = 1 };
@@ -56,17 +57,43 @@ __device__ inline float quick_gelu_grad(float u) {
     return s * (1.0f + 1.702f * u * (1.0f - s));
 }
 
-// [hi | lo] pair of an fp32 value for a split-operand GEMM (Tower::split): hi = T(v), lo = T(v - hi), so that hi + lo carries 22 bits.
-// The value passes through an opaque register first: with -ffp-contract=fast (hipcc's default) the compiler may form `hi` from the
-// UNROUNDED product that made v (v_fma_mixlo_f16: one rounding) in one place and from the rounded v in another; on exact ties the two
-// disagree and hi + lo is then off by a whole ulp of T (measured in round 3: 1 element in ~8 000 of the exact attention output).
+// Split operands (Tower::split_mode).  A forward GEMM's A operand v is stored as hi = T(v) in the ordinary operand buffer plus the
+// remainder lo = v - hi in a SECOND buffer with the same row stride in BYTES, in one of two forms:
+//   LO_F16: lo as T.  hi + lo carries 22 bits; the GEMM runs a second pass over lo against the same weights (what the text tower uses: it
+//           needs every bit, tests/precision_ablation.py);
+//   LO_F8 : lo * 2^LO8_SHIFT as OCP e4m3 (the first K bytes of each row; the rest of the row is padding so that byte offsets into hi and lo
+//           agree).  The second pass runs on the MX-scaled fp8 matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4, 2x the fp16 rate, K = 128
+//           per instruction) against an e4m3 copy of the weights: the pair carries ~15 bits and the pass costs half of the first one.
+// LO8_SHIFT: |lo| <= 2^-11 |v|, so lo * 2^12 stays below e4m3's maximum 448 for |v| < 224 (beyond: saturates, the element falls back towards
+// fp16 precision) and inside e4m3's normal range (>= 2^-6) for |v| >= 2^-7.  The hardware conversion returns NaN beyond 448
+// (tools/probes/mfma_f8.py): the clamp is explicit.
+enum LoMode : int { LO_NONE = 0, LO_F16 = 1, LO_F8 = 2 };
+constexpr int LO8_SHIFT = 12;
+constexpr int LO8_SCALE_E8M0 = 127 - LO8_SHIFT;  // the MX block scale 2^-LO8_SHIFT of the fp8 pass's activation operand
+
+// hi = T(v); returns the fp32 remainder v - hi.  The value passes through an opaque register first: with -ffp-contract=fast (hipcc's
+// default) the compiler may form `hi` from the UNROUNDED product that made v (v_fma_mixlo_f16: one rounding) in one place and from the
+// rounded v in another; on exact ties the two disagree and hi + lo is then off by a whole ulp of T (measured in round 3: 1 element in
+// ~8 000 of the exact attention output).
 template <typename E>
-__device__ inline void split_hi_lo(float v, E& hi, E& lo) {
+__device__ inline float split_rem(float v, E& hi) {
     asm volatile("" : "+v"(v));
     hi = (E)v;
     float h = (float)hi;
     asm volatile("" : "+v"(h));
-    lo = (E)(v - h);
+    return v - h;
+}
+template <typename E>
+__device__ inline void split_hi_lo(float v, E& hi, E& lo) {
+    lo = (E)split_rem(v, hi);
+}
+// four remainders -> four e4m3 bytes (byte j = element j), scaled by 2^LO8_SHIFT, saturating
+__device__ inline uint32_t pack_lo8(float a, float b, float c, float d) {
+    constexpr float S = (float)(1 << LO8_SHIFT);
+    auto sat = [](float x) { return __builtin_fminf(__builtin_fmaxf(x * S, -448.f), 448.f); };
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(sat(a), sat(b), 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(sat(c), sat(d), w, true);
+    return (uint32_t)w;
 }
 
 __device__ inline float wave_sum(float v) {

@@ -73,33 +73,44 @@ int launch_patchify(int dtype, const float* images, void* patches, int B, int S,
 
 // Split-operand form (exact mode): row = [hi | lo] of 2 ldk elements, lo = pixel - (float)hi; one thread per pixel slot.
 template <typename T>
-__global__ __launch_bounds__(256) void patchify_split_kernel(const float* __restrict__ img, typename T::elem* __restrict__ out, int B, int S, int p, int ldk) {
+__global__ __launch_bounds__(256) void patchify_split_kernel(const float* __restrict__ img, typename T::elem* __restrict__ out, void* __restrict__ out_lo, int lo_mode,
+                                                             int B, int S, int p, int ldk) {
     using elem = typename T::elem;
     const int g = S / p, K0 = 3 * p * p;
-    const size_t total = (size_t)B * g * g * ldk;
+    const size_t total = (size_t)B * g * g * (ldk / 4);  // four consecutive k per thread: one 4-byte store of e4m3 remainders
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int k = idx % ldk;
-        const size_t patch = idx / ldk;
-        float v = 0.f;
-        if (k < K0) {
-            const int c = k / (p * p), py = (k / p) % p, px = k % p;
-            const int gx = patch % g, gy = (patch / g) % g;
-            const size_t b = patch / ((size_t)g * g);
-            v = img[((b * 3 + c) * S + gy * p + py) * S + gx * p + px];
+        const int k0 = (int)(idx % (ldk / 4)) * 4;
+        const size_t patch = idx / (ldk / 4);
+        const int gx = patch % g, gy = (patch / g) % g;
+        const size_t b = patch / ((size_t)g * g);
+        float rem[4];
+        typename T::vec4 hv, lv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j;
+            float v = 0.f;
+            if (k < K0) {
+                const int c = k / (p * p), py = (k / p) % p, px = k % p;
+                v = img[((b * 3 + c) * S + gy * p + py) * S + gx * p + px];
+            }
+            elem hi;
+            rem[j] = split_rem(v, hi);
+            hv[j] = hi;
+            lv[j] = (elem)rem[j];
         }
-        elem hi, lo;
-        split_hi_lo(v, hi, lo);
-        out[patch * 2 * ldk + k] = hi;
-        out[patch * 2 * ldk + ldk + k] = lo;
+        *(typename T::vec4*)(out + patch * ldk + k0) = hv;
+        if (lo_mode == LO_F8) *(uint32_t*)((char*)out_lo + patch * ldk * 2 + k0) = pack_lo8(rem[0], rem[1], rem[2], rem[3]);
+        else *(typename T::vec4*)((elem*)out_lo + patch * ldk + k0) = lv;
     }
 }
 
-int launch_patchify_split(int dtype, const float* images, void* patches, int B, int S, int p, int ldk, hipStream_t s) {
-    ARG_CHECK(images && patches && B > 0 && S > 0 && p > 0 && S % p == 0 && ldk >= 3 * p * p, "patchify: bad arguments S=%d p=%d ldk=%d", S, p, ldk);
-    const size_t total = (size_t)B * (S / p) * (S / p) * ldk;
+int launch_patchify_split(int dtype, const float* images, void* patches, void* patches_lo, int lo_mode, int B, int S, int p, int ldk, hipStream_t s) {
+    ARG_CHECK(images && patches && patches_lo && B > 0 && S > 0 && p > 0 && S % p == 0 && ldk >= 3 * p * p && ldk % 4 == 0, "patchify: bad arguments S=%d p=%d ldk=%d", S, p, ldk);
+    ARG_CHECK(lo_mode == LO_F16 || lo_mode == LO_F8, "patchify: bad lo_mode %d", lo_mode);
+    const size_t total = (size_t)B * (S / p) * (S / p) * (ldk / 4);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (dtype == DT_BF16) hipLaunchKernelGGL(patchify_split_kernel<BF16>, dim3(grid), dim3(256), 0, s, images, (__bf16*)patches, B, S, p, ldk);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(patchify_split_kernel<F16>, dim3(grid), dim3(256), 0, s, images, (_Float16*)patches, B, S, p, ldk);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(patchify_split_kernel<BF16>, dim3(grid), dim3(256), 0, s, images, (__bf16*)patches, patches_lo, lo_mode, B, S, p, ldk);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(patchify_split_kernel<F16>, dim3(grid), dim3(256), 0, s, images, (_Float16*)patches, patches_lo, lo_mode, B, S, p, ldk);
     else { set_error("patchify: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
     HIP_TRY(hipGetLastError());
     return MUDPT_OK;

@@ -11,6 +11,8 @@
 // ds_read_b128 touches 16 distinct slots of the 256-byte bank row (conflict free).
 // The MFMA computes the transposed tile D[n][m] = B-frag x A-frag so that a lane owns 4 consecutive
 // output columns of one row: the epilogue stores 8 (T) or 16 (fp32) contiguous bytes per lane.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace mudpt {
@@ -66,14 +68,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
         bsrc[i] = Bw + (size_t)r * p.ldb + schunk * 8;
     }
 
+    // Split A operand (common.h LoMode): after the nt1 K-tiles of the first pass (hi against B) a second pass contracts the low half --
+    // LO_F16: nt1 more tiles of A_lo against the same B; LO_F8: K / 128 tiles of e4m3 bytes, A_lo against B8.  Both low buffers have the row
+    // stride of their T counterparts IN BYTES, and every K-tile of either pass is 128 bytes of a row: a tile of the second pass is the
+    // first pass's address plus a uniform byte offset (dA / dB) -- the staging below is otherwise unchanged.
+    const int nt1 = kspan / BK;
+    const bool f8 = p.lo_mode == LO_F8;
+    const int nt = nt1 + (p.lo_mode == LO_NONE ? 0 : (f8 ? nt1 / 2 : nt1));
+    const ptrdiff_t dA = p.A_lo ? (const char*)p.A_lo - (const char*)p.A : 0;
+    const ptrdiff_t dB = f8 ? (const char*)p.B8 - (const char*)p.B : 0;
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE_BYTES;
+        const bool second = kt >= nt1;
+        const ptrdiff_t oa = second ? dA + (ptrdiff_t)(kt - nt1) * 128 : (ptrdiff_t)kt * 128;
+        const ptrdiff_t ob = second ? dB + (ptrdiff_t)(kt - nt1) * 128 : (ptrdiff_t)kt * 128;
 #pragma unroll
         for (int i = 0; i < IA; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(base + (wave + NW * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)asrc[i] + oa), (lptr_t)(base + (wave + NW * i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < IB; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + kt * BK), (lptr_t)(base + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)bsrc[i] + ob), (lptr_t)(base + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[TM][TN];
@@ -96,12 +110,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     // plain double buffer (2 workgroups per CU hide each other's waits); NS = 4 is for grids smaller than the chip (the text
     // tower's 99-row GEMMs: a handful of workgroups, each a pure latency chain over K).
     static_assert(NS >= 2 && (NS & (NS - 1)) == 0, "ring depth must be a power of two");
-    const int nt = kspan / BK;
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st)
         if (st < nt) stage(st, st);
 
-    for (int kt = 0; kt < nt; ++kt) {
+    // One K-tile: wait for it, refill the stage freed by the previous tile, multiply.  The e4m3 tiles of the second pass run in their OWN loop
+    // after the fp16 tiles (same ring, same staging), not behind a branch in one loop: a diamond around the in-place accumulation costs a
+    // second set of accumulator registers (gemm_pp.hip; here it made the 256 x 256 patch-embed tile 3.4x slower).
+    auto tile = [&](auto f8tag, int kt) {
         const int cur = kt & (NS - 1);
         // tile kt has landed once at most the NS - 2 younger stages are outstanding (loads retire in issue order)
         if (kt + NS - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (IA + IB)) : "memory");
@@ -109,20 +125,41 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
         __syncthreads();  // ... for every wave; and every wave is done reading the stage refilled next (read in step kt - 1)
         if (kt + NS - 1 < nt) stage((kt + NS - 1) & (NS - 1), kt + NS - 1);
         const char* base = smem + cur * STAGE_BYTES;
+        if constexpr (decltype(f8tag)::value) {
+            // e4m3 tile: 128 k per row; lane (frow, fq) owns bytes 32 fq .. 32 fq + 31 of its row = chunks 2 fq, 2 fq + 1 (swizzled like every
+            // tile), ONE K = 128 matrix instruction per sub-tile pair (operand pairing and block scales: tools/probes/mfma_f8_layout.py)
+            const int c = ((2 * fq) ^ sw) * 16;
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            i32x8 b8[TN];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int c = ((ks * 4 + fq) ^ sw) * 16;
-            vec8 af[TM], bf[TN];
+            for (int j = 0; j < TN; ++j)
+                b8[j] = __builtin_shufflevector(*(const i32x4*)(base + boff[j] + c), *(const i32x4*)(base + boff[j] + (c ^ 16)), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const vec8*)(base + aoff[i] + c);
+            for (int i = 0; i < TM; ++i) {
+                const i32x8 a8 = __builtin_shufflevector(*(const i32x4*)(base + aoff[i] + c), *(const i32x4*)(base + aoff[i] + (c ^ 16)), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *(const vec8*)(base + boff[j] + c);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8[j], a8, acc[i][j], 0, 0, 0, p.b8_scale, 0, LO8_SCALE_E8M0);
+            }
+        } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int ks = 0; ks < 2; ++ks) {
+                const int c = ((ks * 4 + fq) ^ sw) * 16;
+                vec8 af[TM], bf[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma16(bf[j], af[i], acc[i][j]);
+                for (int i = 0; i < TM; ++i) af[i] = *(const vec8*)(base + aoff[i] + c);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *(const vec8*)(base + boff[j] + c);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma16(bf[j], af[i], acc[i][j]);
+            }
         }
-    }
+    };
+    const int nt16 = f8 ? nt1 : nt;  // LO_F16: the second pass is nt1 more tiles of the same kind
+    for (int kt = 0; kt < nt16; ++kt) tile(std::false_type{}, kt);
+    for (int kt = nt16; kt < nt; ++kt) tile(std::true_type{}, kt);
 
     // ---- epilogue: lane holds out[m][n .. n+3], m = sub-tile row (lane & 15), n = 4 * (lane >> 4) ----
 #pragma unroll
@@ -151,12 +188,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
             } else if constexpr (EPI == EPI_GELU) {
                 typename T::vec4 u = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
                 *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = u;
-                if (p.out1_lo) {  // split operand: the next GEMM contracts over [hi | lo] against [W | W]
+                if (p.out1_lo) {  // split operand (common.h LoMode): the next GEMM's second pass contracts over the low half
                     typename T::vec4 g, lo;
+                    float rem[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { elem hv, lv; split_hi_lo(quick_gelu(v[c]), hv, lv); g[c] = hv; lo[c] = lv; }
+                    for (int c = 0; c < 4; ++c) { elem hv; rem[c] = split_rem(quick_gelu(v[c]), hv); g[c] = hv; lo[c] = (elem)rem[c]; }
                     *(typename T::vec4*)((elem*)p.out1 + orow * p.ldo1 + n) = g;
-                    *(typename T::vec4*)((elem*)p.out1_lo + orow * p.ldo1 + n) = lo;
+                    if (p.out1_lo_mode == LO_F8) *(uint32_t*)((char*)p.out1_lo + orow * p.ldo1 * 2 + n) = pack_lo8(rem[0], rem[1], rem[2], rem[3]);
+                    else *(typename T::vec4*)((elem*)p.out1_lo + orow * p.ldo1 + n) = lo;
                 } else {
                     typename T::vec4 g = {(elem)quick_gelu(v[0]), (elem)quick_gelu(v[1]), (elem)quick_gelu(v[2]), (elem)quick_gelu(v[3])};
                     *(typename T::vec4*)((elem*)p.out1 + orow * p.ldo1 + n) = g;
@@ -265,7 +304,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // the reference's training batch of 4, K = 2304 / 3072): a 128 x 64 tile per workgroup leaves 2/3 of the CUs idle while every workgroup
 // walks 36-48 K-steps.  S slices of K fill the chip; their fp32 partials go through the caller's scratch and are summed in slice order.
 static int split_k_slices(int epi, const GemmArgs& a, const GemmOpts& o) {
-    if (!(epi == EPI_STORE || epi == EPI_STORE_F32) || !o.scratch || (o.variant & 0xff) != 0) return 1;
+    if (!(epi == EPI_STORE || epi == EPI_STORE_F32) || !o.scratch || (o.variant & 0xff) != 0 || a.lo_mode != LO_NONE) return 1;
     static PerDevice pd;
     const int dev = current_device();
     if (!pd.done[dev]) {
@@ -299,6 +338,14 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const Gemm
     ARG_CHECK(a.ldo0 >= a.N && a.ldo0 % 4 == 0, "gemm: bad ldo0 %d", a.ldo0);
     ARG_CHECK(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && ((uintptr_t)a.out0 % 16 == 0), "gemm: operands must be 16-byte aligned");
     if (epi == EPI_GELU) ARG_CHECK(a.out1 && a.ldo1 >= a.N && a.ldo1 % 4 == 0, "gemm: gelu epilogue needs out1");
+    ARG_CHECK(!a.out1_lo || a.out1_lo_mode == LO_F16 || a.out1_lo_mode == LO_F8, "gemm: bad out1_lo_mode %d", a.out1_lo_mode);
+    ARG_CHECK(a.lo_mode == LO_NONE || a.lo_mode == LO_F16 || a.lo_mode == LO_F8, "gemm: bad lo_mode %d", a.lo_mode);
+    if (a.lo_mode != LO_NONE) ARG_CHECK(a.A_lo && (uintptr_t)a.A_lo % 16 == 0, "gemm: a split operand needs its low half (16-byte aligned)");
+    if (a.lo_mode == LO_F8) {
+        ARG_CHECK(dtype == DT_F16, "gemm: the e4m3 second pass exists for fp16 operands only");
+        ARG_CHECK(a.B8 && (uintptr_t)a.B8 % 16 == 0 && a.K % 128 == 0, "gemm: the e4m3 second pass needs B8 and K %% 128 == 0 (K = %d)", a.K);
+        ARG_CHECK(a.b8_scale > 0 && a.b8_scale < 255, "gemm: bad E8M0 weight scale %d", a.b8_scale);
+    }
     if (epi == EPI_RESIDUAL || epi == EPI_GELU_BWD) ARG_CHECK(a.aux && a.ldaux >= a.N && a.ldaux % 4 == 0, "gemm: epilogue needs aux");
     if (epi == EPI_PATCH) ARG_CHECK(a.pos && a.patches > 0 && a.seq_len > a.patches && a.M % a.patches == 0, "gemm: bad patch epilogue args");
     GemmArgs b = a;

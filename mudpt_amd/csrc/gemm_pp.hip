@@ -19,6 +19,8 @@
 //  * Buffer descriptors bound-check the operand reads (rows >= M read as zero): no clamping, ragged M is free.
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace mudpt {
@@ -41,9 +43,16 @@ __device__ inline void vmcnt() {
 // sc1 / sc0 sc1 stores are 8-60 % SLOWER (fc 315 -> 515 us: the L2 no longer absorbs the store bursts), nt stores and nt aux loads
 // are within +-1 % over the 8 GEMMs of a block.  Counters with nt stores over the whole step (round 2, separate --pmc passes): fc's HBM-side reads 412 -> 332 MB per launch, but its
 // writes 632 -> 900 MB (partial lines are no longer combined in the L2) and the step 25.10 -> 25.38 ms.  Plain policy everywhere; the parameters stay for the next experiment.
-constexpr int EPI_GELU_SPLIT = 100;  // EPI_GELU with out1 as a split operand: out1 = hi(gelu(u)), out1_lo = the remainder (exact mode, Tower::split)
+constexpr int EPI_GELU_SPLIT = 100;   // EPI_GELU with out1 as a split operand: out1 = hi(gelu(u)), out1_lo = the remainder as T (common.h LO_F16)
+constexpr int EPI_GELU_SPLIT8 = 101;  // ... the remainder as e4m3 bytes (LO_F8)
 
-template <typename T, int EPI, int ST = 0, int LD = 0>
+// Split A operand (common.h LoMode; GemmArgs::A_lo): a tile's K loop is two passes -- K / 64 steps of A against B, then the low half:
+// LO_F16: K / 64 more steps of A_lo against the same B (fp16 MFMA; the text tower, which needs all 22 bits);
+// LO_F8 (template F8): K / 128 steps of e4m3 bytes, A_lo against B8, on v_mfma_scale_f32_16x16x128_f8f6f4 -- a K-step is again 128 bytes per row and
+// 64 KiB per stage, 32 matrix instructions of twice the length per wave: the same pipe time, DMA volume, LDS image, swizzle and vmcnt
+// accounting as an fp16 step.  Both low buffers have the row stride of their T counterparts in bytes, so only the buffer descriptors change
+// between the passes.
+template <typename T, int EPI, bool F8 = false, int ST = 0, int LD = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int ntiles, int rem_half) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
@@ -55,7 +64,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     const int wr = w >> 2, wc = w & 3;
     const int frow = lane & 15, fq = lane >> 4;
 
-    const int nkt = p.K >> 6;
+    const int nkt1 = p.K >> 6;                                                       // K-steps of the first pass
+    const int nkt = nkt1 + (p.lo_mode == LO_NONE ? 0 : (F8 ? nkt1 >> 1 : nkt1));     // ... of both passes of a tile
     const int G = gridDim.x;
     // Work items of this block: my_full whole 256 x 256 tiles (b, b + G, ...), then -- when the host split the last, partial
     // wave of tiles (rem_half of them, 2 rem_half <= G) -- one HALF tile of 128 rows x 256 columns: blocks b and b + rem_half
@@ -67,19 +77,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((size_t)p.M * p.lda * 2 < 0xffffffffull ? (size_t)p.M * p.lda * 2 : 0xffffffffull), 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((size_t)p.N * p.ldb * 2 < 0xffffffffull ? (size_t)p.N * p.ldb * 2 : 0xffffffffull), 0x00020000);
+    // second pass: the low half of A; B again or its e4m3 copy (same extents in bytes)
+    const auto rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A_lo ? p.A_lo : p.A), 0, (int)((size_t)p.M * p.lda * 2 < 0xffffffffull ? (size_t)p.M * p.lda * 2 : 0xffffffffull), 0x00020000);
+    const auto rsB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(F8 ? p.B8 : p.B), 0, (int)((size_t)p.N * p.ldb * 2 < 0xffffffffull ? (size_t)p.N * p.ldb * 2 : 0xffffffffull), 0x00020000);
 
     // epilogue operands through bounds-checked descriptors as well (out-of-range lanes get offset OOB: dropped / read 0)
-    static_assert(EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_BWD || EPI == EPI_STORE_F32, "epilogue not built for gemm_pp");
-    constexpr bool GELU = (EPI == EPI_GELU || EPI == EPI_GELU_SPLIT);
+    static_assert(EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_SPLIT8 || EPI == EPI_GELU_BWD || EPI == EPI_STORE_F32, "epilogue not built for gemm_pp");
+    constexpr bool GELU = (EPI == EPI_GELU || EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_SPLIT8);
     constexpr int OOB = (int)0x80000000;
     constexpr bool OUT_F32 = (EPI == EPI_STORE_F32);
     // B fragment rows: permuted (a lane ends up with 16 consecutive columns = 32 bytes of T) for the T outputs, natural
     // (4 consecutive columns per sub-tile = 16 bytes of fp32) for the fp32 output; see the epilogue.
     constexpr bool NAT = OUT_F32;
-    constexpr int NST = (EPI == EPI_STORE || EPI == EPI_GELU_BWD) ? 16 : (EPI == EPI_GELU_SPLIT ? 48 : 32);  // stores per wave per tile, exact
+    constexpr int NST = (EPI == EPI_STORE || EPI == EPI_GELU_BWD) ? 16 : (EPI == EPI_GELU_SPLIT ? 48 : (EPI == EPI_GELU_SPLIT8 ? 40 : 32));  // stores per wave per tile, exact
     const auto rsOut0 = __builtin_amdgcn_make_buffer_rsrc(p.out0, 0, p.M * p.ldo0 * (OUT_F32 ? 4 : 2), 0x00020000);
     const auto rsOut1 = __builtin_amdgcn_make_buffer_rsrc(p.out1, 0, GELU ? p.M * p.ldo1 * 2 : 0, 0x00020000);
-    const auto rsOut1Lo = __builtin_amdgcn_make_buffer_rsrc(p.out1_lo, 0, EPI == EPI_GELU_SPLIT ? p.M * p.ldo1 * 2 : 0, 0x00020000);
+    const auto rsOut1Lo = __builtin_amdgcn_make_buffer_rsrc(p.out1_lo, 0, (EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_SPLIT8) ? p.M * p.ldo1 * 2 : 0, 0x00020000);
     const auto rsAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0, EPI == EPI_GELU_BWD ? p.M * p.ldaux * 2 : 0, 0x00020000);
     const auto rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
     bool epi_pending = false;  // the previous step ended with an epilogue: NST stores sit in the VMEM queue
@@ -142,7 +155,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     };
     // The step being prefetched ("next"): k-tile n_kt of this block's n_it-th item; all scalar, updated incrementally
     // (no division in the loop: the DMA issue sits in the read section that must stay shorter than 16 MFMAs).
-    int n_kt = 0, n_it = 0, n_baseA = 0, n_baseB = 0;
+    int n_kt = 0, n_it = 0, n_baseA = 0, n_baseB = 0, n_soff = 0;  // n_soff: byte offset of the step's 128 bytes inside its pass's rows
+    bool n_second = false;  // the step being prefetched belongs to the second pass (low half of A): the *2 descriptors
     bool n_half = false;  // the item being prefetched is the half tile: its 128 A rows are unit 0 alone, unit 3 is not issued
     auto set_next_item = [&](int it) {
         int tm, tn, h;
@@ -154,9 +168,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
         n_baseB = tn * 256 * p.ldb * 2;
     };
     auto advance_next = [&]() {
+        n_soff += 128;
         if (++n_kt == nkt) {
-            n_kt = 0;
+            n_kt = 0; n_soff = 0; n_second = false;
             if ((++n_it) * nkt < total) set_next_item(n_it);
+        } else if (n_kt == nkt1) {
+            n_soff = 0; n_second = true;
         }
     };
     // issue unit u of the next step into LDS stage `stage`
@@ -166,12 +183,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
         char* dst = smem + stage * STAGE + (isA ? 0 : BOFF);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (lptr_t)(dst + grp[u][q] * 1024), 16, lane_off[u][q] + base, n_kt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? (n_second ? rsA2 : rsA) : (n_second ? rsB2 : rsB), (lptr_t)(dst + grp[u][q] * 1024), 16, lane_off[u][q] + base, n_soff, 0, 0);
     };
 
     // ---- fragment read offsets -----------------------------------------------------------------------------------
     const int sw = frow & 7;
     const int c0 = (fq ^ sw) << 4;           // k-step 0 chunk byte offset; k-step 1 is c0 ^ 64
+    const int c8 = ((2 * fq) ^ sw) << 4;     // e4m3 step: the lane's 32 bytes k = 32 fq .. 32 fq + 31 are chunks 2 fq (c8) and 2 fq + 1 (c8 ^ 16)
+    int ca = c0, cb = c0 ^ 64;               // the two chunk offsets of the step being computed
     const int a_base = (wr * 128 + frow) * 128;
     const int b_base = BOFF + (NAT ? wc * 64 + frow : wc * 64 + (frow >> 2) * 16 + (frow & 3)) * 128;
     constexpr int BJ = NAT ? 2048 : 512;  // byte step between the B fragments of consecutive sub-tiles
@@ -193,37 +212,46 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
-    vec8 af[4][2], bf[4][2];  // A fragments of the current quadrant pair, B fragments of all 4 sub-tiles, 2 k-steps each
-    int kt = 0, c_it = 0;      // the step being computed: k-tile kt of this block's c_it-th tile
+    // A fragments of the current quadrant pair, B fragments of all 4 sub-tiles: 32 bytes each = the two k-steps of an fp16 step (halves 0 / 1)
+    // or the ONE 8-register operand of an e4m3 step -- kept as 8-register tuples so that the latter needs no copies
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    i32x8 af[4], bf[4];
+    auto half = [](const i32x8& v, int ks) -> vec8 {
+        return __builtin_bit_cast(vec8, ks ? __builtin_shufflevector(v, v, 4, 5, 6, 7) : __builtin_shufflevector(v, v, 0, 1, 2, 3));
+    };
+    int c_it = 0;              // the tile being computed: this block's c_it-th item
 
-    // 16 MFMAs of one accumulator quadrant: rows 16 (i0 + i), sub-tiles j0, j0 + 1
-    auto mfma_quadrant = [&](int i0, int j0) {
+    // 16 MFMAs (8 of twice the length in an e4m3 step) of one accumulator quadrant: rows 16 (i0 + i), sub-tiles j0, j0 + 1
+    auto mfma_quadrant = [&](auto f8tag, int i0, int j0) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if constexpr (decltype(f8tag)::value) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i0 + i][j0 + j] = T::mfma16(bf[j0 + j][ks], af[i][ks], acc[i0 + i][j0 + j]);
+                for (int j = 0; j < 2; ++j)
+                    acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[j0 + j], af[i], acc[i0 + i][j0 + j], 0, 0, 0, p.b8_scale, 0, LO8_SCALE_E8M0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i0 + i][j0 + j] = T::mfma16(half(bf[j0 + j], ks), half(af[i], ks), acc[i0 + i][j0 + j]);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto read_a = [&](const char* st, int i0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i][0] = *(const vec8*)(st + a_base + (i0 + i) * 2048 + c0);
-            af[i][1] = *(const vec8*)(st + a_base + (i0 + i) * 2048 + (c0 ^ 64));
-        }
+        for (int i = 0; i < 4; ++i)
+            af[i] = __builtin_shufflevector(*(const i32x4*)(st + a_base + (i0 + i) * 2048 + ca), *(const i32x4*)(st + a_base + (i0 + i) * 2048 + cb), 0, 1, 2, 3, 4, 5, 6, 7);
     };
     auto read_b = [&](const char* st, int j0) {
 #pragma unroll
-        for (int j = j0; j < j0 + 2; ++j) {
-            bf[j][0] = *(const vec8*)(st + b_base + j * BJ + c0);
-            bf[j][1] = *(const vec8*)(st + b_base + j * BJ + (c0 ^ 64));
-        }
+        for (int j = j0; j < j0 + 2; ++j)
+            bf[j] = __builtin_shufflevector(*(const i32x4*)(st + b_base + j * BJ + ca), *(const i32x4*)(st + b_base + j * BJ + cb), 0, 1, 2, 3, 4, 5, 6, 7);
     };
-
     auto epilogue = [&]() {
             // ---- epilogue of this output tile: lane owns out[m][n0 .. n0 + 15], m = sub-tile row (lane & 15) ----
             // Branch-free: buffer descriptors drop out-of-range lanes (ragged M, N edge), so every wave issues exactly
@@ -293,6 +321,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut1, off1, 0, ST);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut1, off1, 16, ST);
                     }
+                    if constexpr (EPI == EPI_GELU_SPLIT8) {
+                        u32x4 l8;
+                        float rem[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                elem hv;
+                                rem[c] = split_rem(quick_gelu(acc[i][j][c]), hv);
+                                if (j < 2) o0[4 * j + c] = hv; else o1[4 * (j - 2) + c] = hv;
+                            }
+                            l8[j] = pack_lo8(rem[0], rem[1], rem[2], rem[3]);
+                        }
+                        const int off1 = row_off(i, p.ldo1, 2, n);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut1, off1, 0, ST);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut1, off1, 16, ST);
+                        // e4m3 remainders: byte column n of a row whose stride in bytes is that of out1 (2 ldo1)
+                        __builtin_amdgcn_raw_buffer_store_b128(l8, rsOut1Lo, (n < p.N ? m_base * p.ldo1 * 2 + n : OOB) + i * (32 * p.ldo1), 0, ST);
+                    }
                     if constexpr (EPI == EPI_GELU_SPLIT) {
                         vec8 l0, l1;
 #pragma unroll
@@ -317,92 +364,116 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
             epi_pending = true;
     };
 
-    const int full_steps = my_full * nkt;
-    for (int s = 0; s < full_steps; ++s) {
+    // One K-step of a full tile (4 phases) / of the half tile (2 phases), in two flavours: an fp16 step and an e4m3 step of the second pass.
+    // The two flavours are SEPARATE loops per tile (first pass, then second pass), not one loop with a branch around the MFMAs: a diamond
+    // around an in-place accumulation made the compiler give every quadrant a second set of accumulator registers (+34 VGPRs, copies).
+    int s = 0;  // the block's running K-step count (stage = s & 1)
+    auto full_step = [&](auto f8tag) {
+        constexpr bool F8S = decltype(f8tag)::value;
         const int cur = s & 1;
         const char* st = smem + cur * STAGE;
         const bool nxt = s + 1 < total;
-        {
-            // ================= phase 0: quadrant (rows 0-63, sub-tiles 0-1) =================
-            read_a(st, 0);
-            read_b(st, 0);
-            // retire unit 2 of this step (read in phase 1): younger operations = unit 3 [2] (+ the last epilogue's stores) (+ unit 0' [2])
-            if (nxt) {
-                issue(0, cur ^ 1);
-                if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
-            } else {
-                if (epi_pending) vmcnt<NST + 2>(); else vmcnt<2>();
-            }
-            __builtin_amdgcn_s_barrier();
-            mfma_quadrant(0, 0);
-            __builtin_amdgcn_s_barrier();
-            // ================= phase 1: quadrant (rows 0-63, sub-tiles 2-3) =================
-            read_b(st, 2);
-            // retire unit 3 of this step (read in phase 2): younger = (stores) + unit 0' [2] + unit 1' [2]
-            if (nxt) {
-                issue(1, cur ^ 1);
-                if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
-            } else {
-                if (epi_pending) vmcnt<NST>(); else vmcnt<0>();
-            }
-            epi_pending = false;  // phase 3's wait (units 0', 1' are younger than the stores) covers the stores themselves
-            __builtin_amdgcn_s_barrier();
-            mfma_quadrant(0, 2);
-            __builtin_amdgcn_s_barrier();
-            // ================= phase 2: quadrant (rows 64-127, sub-tiles 2-3) =================
-            read_a(st, 4);
-            if (nxt) issue(2, cur ^ 1);
-            __builtin_amdgcn_s_barrier();
-            mfma_quadrant(4, 2);
-            __builtin_amdgcn_s_barrier();
-            // ================= phase 3: quadrant (rows 64-127, sub-tiles 0-1) =================
-            // retires units 0, 1 of the next step (read in its phase 0); a half tile has no unit 3
-            if (nxt) {
-                if (!n_half) { issue(3, cur ^ 1); advance_next(); VMCNT(4); } else { advance_next(); VMCNT(2); }
-            }
-            __builtin_amdgcn_s_barrier();
-            mfma_quadrant(4, 0);
-            __builtin_amdgcn_s_barrier();
+        ca = F8S ? c8 : c0;
+        cb = F8S ? (c8 ^ 16) : (c0 ^ 64);
+        // ================= phase 0: quadrant (rows 0-63, sub-tiles 0-1) =================
+        read_a(st, 0);
+        read_b(st, 0);
+        // retire unit 2 of this step (read in phase 1): younger operations = unit 3 [2] (+ the last epilogue's stores) (+ unit 0' [2])
+        if (nxt) {
+            issue(0, cur ^ 1);
+            if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
+        } else {
+            if (epi_pending) vmcnt<NST + 2>(); else vmcnt<2>();
         }
-        if (++kt == nkt) { kt = 0; epilogue(); }
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(f8tag, 0, 0);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase 1: quadrant (rows 0-63, sub-tiles 2-3) =================
+        read_b(st, 2);
+        // retire unit 3 of this step (read in phase 2): younger = (stores) + unit 0' [2] + unit 1' [2]
+        if (nxt) {
+            issue(1, cur ^ 1);
+            if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
+        } else {
+            if (epi_pending) vmcnt<NST>(); else vmcnt<0>();
+        }
+        epi_pending = false;  // phase 3's wait (units 0', 1' are younger than the stores) covers the stores themselves
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(f8tag, 0, 2);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase 2: quadrant (rows 64-127, sub-tiles 2-3) =================
+        read_a(st, 4);
+        if (nxt) issue(2, cur ^ 1);
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(f8tag, 4, 2);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase 3: quadrant (rows 64-127, sub-tiles 0-1) =================
+        // retires units 0, 1 of the next step (read in its phase 0); a half tile has no unit 3
+        if (nxt) {
+            if (!n_half) { issue(3, cur ^ 1); advance_next(); VMCNT(4); } else { advance_next(); VMCNT(2); }
+        }
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(f8tag, 4, 0);
+        __builtin_amdgcn_s_barrier();
+        ++s;
+    };
+    auto half_step = [&](auto f8tag) {
+        constexpr bool F8S = decltype(f8tag)::value;
+        const int cur = s & 1;
+        const char* st = smem + cur * STAGE;
+        const bool nxt = s + 1 < total;
+        ca = F8S ? c8 : c0;
+        cb = F8S ? (c8 ^ 16) : (c0 ^ 64);
+        // ---- a K-step of the half tile: 64 rows per wave, two phases, units 0 (A), 1, 2 (B) only ----
+        // ================= phase 0: (rows 0-63, sub-tiles 0-1) =================
+        read_a(st, 0);
+        read_b(st, 0);
+        // retire unit 2 of this step (read in phase 1): younger = (the last full tile's stores) + units 0', 1' [4]
+        if (nxt) {
+            issue(0, cur ^ 1);
+            issue(1, cur ^ 1);
+            if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
+        } else {
+            if (epi_pending) vmcnt<NST>(); else vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(f8tag, 0, 0);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase 1: (rows 0-63, sub-tiles 2-3) =================
+        read_b(st, 2);
+        if (nxt) { issue(2, cur ^ 1); advance_next(); VMCNT(2); }  // retires units 0', 1' (and any stores before them)
+        epi_pending = false;
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(f8tag, 0, 2);
+        __builtin_amdgcn_s_barrier();
+        ++s;
+    };
+    const int nkt2 = nkt - nkt1;  // K-steps of the second pass (0 without a split operand)
+    for (int it = 0; it < my_full; ++it) {
+        if constexpr (F8) {
+            for (int k = 0; k < nkt1; ++k) full_step(std::false_type{});
+            for (int k = 0; k < nkt2; ++k) full_step(std::true_type{});
+        } else {
+            for (int k = 0; k < nkt; ++k) full_step(std::false_type{});  // LO_F16: the second pass is nkt1 more steps of the same kind
+        }
+        epilogue();
     }
-    for (int s = full_steps; s < total; ++s) {
-        const int cur = s & 1;
-        const char* st = smem + cur * STAGE;
-        const bool nxt = s + 1 < total;
-        {
-            // ---- a K-step of the half tile: 64 rows per wave, two phases, units 0 (A), 1, 2 (B) only ----
-            // ================= phase 0: (rows 0-63, sub-tiles 0-1) =================
-            read_a(st, 0);
-            read_b(st, 0);
-            // retire unit 2 of this step (read in phase 1): younger = (the last full tile's stores) + units 0', 1' [4]
-            if (nxt) {
-                issue(0, cur ^ 1);
-                issue(1, cur ^ 1);
-                if (epi_pending) vmcnt<NST + 4>(); else vmcnt<4>();
-            } else {
-                if (epi_pending) vmcnt<NST>(); else vmcnt<0>();
-            }
-            __builtin_amdgcn_s_barrier();
-            mfma_quadrant(0, 0);
-            __builtin_amdgcn_s_barrier();
-            // ================= phase 1: (rows 0-63, sub-tiles 2-3) =================
-            read_b(st, 2);
-            if (nxt) { issue(2, cur ^ 1); advance_next(); VMCNT(2); }  // retires units 0', 1' (and any stores before them)
-            epi_pending = false;
-            __builtin_amdgcn_s_barrier();
-            mfma_quadrant(0, 2);
-            __builtin_amdgcn_s_barrier();
+    if (has_half) {
+        if constexpr (F8) {
+            for (int k = 0; k < nkt1; ++k) half_step(std::false_type{});
+            for (int k = 0; k < nkt2; ++k) half_step(std::true_type{});
+        } else {
+            for (int k = 0; k < nkt; ++k) half_step(std::false_type{});
         }
-        if (++kt == nkt) { kt = 0; epilogue(); }
+        epilogue();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the second group's extra barrier
 }
 
-template <typename T, int EPI, int ST = 0, int LD = 0>
+template <typename T, int EPI, bool F8 = false, int ST = 0, int LD = 0>
 static int launch_pp(const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
     constexpr int lds = 2 * 65536;
-    auto kern = gemm_pp_kernel<T, EPI, ST, LD>;
+    auto kern = gemm_pp_kernel<T, EPI, F8, ST, LD>;
     static PerDevice pd;
     const int dev = current_device();
     if (!pd.done[dev]) {
@@ -430,9 +501,24 @@ static int launch_pp(const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
 
 template <typename T>
 static int launch_pp_t(int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
+    if constexpr (T::id == DT_F16) {
+        if (a.lo_mode == LO_F8) {  // the e4m3 second pass: forward GEMMs of a split tower only
+            switch (epi) {
+                case EPI_STORE: return launch_pp<T, EPI_STORE, true>(a, s, o);
+                case EPI_GELU:
+                    if (!a.out1_lo) return launch_pp<T, EPI_GELU, true>(a, s, o);
+                    return a.out1_lo_mode == LO_F8 ? launch_pp<T, EPI_GELU_SPLIT8, true>(a, s, o) : launch_pp<T, EPI_GELU_SPLIT, true>(a, s, o);
+                case EPI_STORE_F32: return launch_pp<T, EPI_STORE_F32, true>(a, s, o);
+            }
+            set_error("gemm_pp: epilogue %d is not built with the e4m3 second pass", epi);
+            return MUDPT_ERR_ARG;
+        }
+    }
     switch (epi) {
         case EPI_STORE: return launch_pp<T, EPI_STORE>(a, s, o);
-        case EPI_GELU: return a.out1_lo ? launch_pp<T, EPI_GELU_SPLIT>(a, s, o) : launch_pp<T, EPI_GELU>(a, s, o);
+        case EPI_GELU:
+            if (!a.out1_lo) return launch_pp<T, EPI_GELU>(a, s, o);
+            return a.out1_lo_mode == LO_F8 ? launch_pp<T, EPI_GELU_SPLIT8>(a, s, o) : launch_pp<T, EPI_GELU_SPLIT>(a, s, o);
         case EPI_GELU_BWD: return launch_pp<T, EPI_GELU_BWD>(a, s, o);
         case EPI_STORE_F32: return launch_pp<T, EPI_STORE_F32>(a, s, o);
     }

@@ -26,7 +26,12 @@ struct GemmArgs {
     const float* bias = nullptr;  // [N] or null
     void* out0 = nullptr; int ldo0 = 0;
     void* out1 = nullptr; int ldo1 = 0;
-    void* out1_lo = nullptr;       // EPI_GELU only: out1_lo (T) = gelu(u) - out1, the low half of a split operand (row stride ldo1)
+    void* out1_lo = nullptr;       // EPI_GELU only: the low half of out1 as a split operand (common.h LoMode; same row stride in bytes as out1)
+    int out1_lo_mode = LO_F16;     // ... its form: LO_F16 (T) or LO_F8 (e4m3 bytes)
+    // Split A operand (common.h): a second pass contracts the low half A_lo (same row stride in bytes as A) against B (lo_mode LO_F16)
+    // or against the e4m3 weights B8 (LO_F8: [N, K] bytes at the row stride of B in bytes, block scale 2^(b8_scale - 127)); K % 128 == 0 then.
+    const void* A_lo = nullptr; int lo_mode = LO_NONE;
+    const void* B8 = nullptr; int b8_scale = 127;
     const void* aux = nullptr; int ldaux = 0;
     int flags = 0;                 // bit 0: no XCD remap of the block id (tuning)
     int patches = 0, seq_len = 0;  // EPI_PATCH: P, L
@@ -55,7 +60,8 @@ struct LnFwdArgs {
     const int* row_index = nullptr;            // optional gather of input rows
     const float* gamma = nullptr; const float* beta = nullptr;
     void* out = nullptr; int ldo = 0;          // T or fp32 (out_f32)
-    void* out_lo = nullptr;                    // optional (T only): y - out, the low half of a split operand (row stride ldo)
+    void* out_lo = nullptr;                    // optional (T only): y - out, the low half of a split operand (row stride of out in bytes)
+    int lo_mode = LO_F16;                      // ... its form (common.h LoMode)
     float* mean = nullptr; float* rstd = nullptr;  // [rows] saved statistics (may be null)
     int rows = 0, d = 0; bool out_f32 = false;
     // Fused residual add + prompt splice (identity row map only): v = x[r] + add[r]; rows (r % ov_L) in
@@ -93,7 +99,8 @@ int launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s, const LaunchProf
 struct AttnArgs {
     const void* qkv = nullptr;  // T [B, L, 3*H*64]
     void* out = nullptr;        // fwd: T [B, L, H*64] (row stride ld_out elements, 0 = H*64)
-    void* out_lo = nullptr;     // fwd, optional: out_lo = O - out, the low half of a split operand (same stride)
+    void* out_lo = nullptr;     // fwd, optional: out_lo = O - out, the low half of a split operand (same row stride in bytes)
+    int lo_mode = LO_F16;       // ... its form (common.h LoMode)
     int ld_out = 0;
     float* lse = nullptr;       // [B, H, Lp] natural-log-sum-exp of the scaled scores (Lp = padded L)
     const void* dout = nullptr; // bwd: T [B, L, H*64]
@@ -120,7 +127,7 @@ struct AttnArgs {
 // Single-query forms for the last block (attention_single.hip): ONE query row per sequence (token row a.sel_rows[b]) against all keys
 // (causal: the first pos + 1).  q_sel / dout_sel / dq_sel are compact [B, H*64]; out_sel has row stride ld_out (optional low half out_lo);
 // the backward writes the k and v thirds of a.dqkv for EVERY row (zeros behind a causal limit) and leaves its q third untouched.
-int launch_attn_fwd_single(int dtype, const AttnArgs& a, const void* q_sel, void* out_sel, void* out_lo, int ld_out, float* lse_sel, hipStream_t s);
+int launch_attn_fwd_single(int dtype, const AttnArgs& a, const void* q_sel, void* out_sel, void* out_lo, int ld_out, float* lse_sel, hipStream_t s);  // out_lo in a.lo_mode
 int launch_attn_bwd_single(int dtype, const AttnArgs& a, const void* q_sel, const void* out_sel, int ld_out, const void* dout_sel, const float* lse_sel,
                            void* dq_sel, hipStream_t s);
 int attn_padded_len(int L);
@@ -139,8 +146,8 @@ int launch_attn_bwd_resident(int dtype, const AttnArgs& a, hipStream_t s, const 
 // ------------------------------------------------------------------------------------------------
 // images fp32 [B,3,H,W] -> patches T [B*P, ldk], columns 3*p*p.. zero  (im2col of the stride-p conv, clip/model.py:527-529)
 int launch_patchify(int dtype, const float* images, void* patches, int B, int image_size, int patch, int ldk, hipStream_t s);
-// the same as a split operand: row = [hi (ldk) | lo (ldk)], lo = pixel - hi (exact mode: the conv weight is stored [W | W])
-int launch_patchify_split(int dtype, const float* images, void* patches, int B, int image_size, int patch, int ldk, hipStream_t s);
+// the same as a split operand: patches = hi, patches_lo = the remainder in lo_mode (common.h LoMode), both with rows of ldk * 2 bytes
+int launch_patchify_split(int dtype, const float* images, void* patches, void* patches_lo, int lo_mode, int B, int image_size, int patch, int ldk, hipStream_t s);
 // x[b, row0 + i, :] = rows[i, :] (+ add[i, :])  for i < n : CLS row, prompt rows, deep-prompt splice.
 int launch_set_rows(float* x, int B, int L, int d, int row0, int n, const float* rows, const float* add, hipStream_t s);
 // dst[r] = src[rows[r]] (gather) / dst[rows[r]] = src[r] (scatter): whole rows of row_bytes (multiple of 16), strides in bytes.

@@ -67,12 +67,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs p) {
             if constexpr (OUT_F32) {
                 ((f32x4*)((float*)p.out + (size_t)r * p.ldo))[i] = y;
             } else {
-                if (p.out_lo) {
+                if (p.out_lo) {  // split operand (common.h): hi here, the remainder as T or as e4m3 in a second buffer with the same row stride in bytes
                     typename T::vec4 o, lo;
+                    float rem[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { elem hv, lv; split_hi_lo(y[j], hv, lv); o[j] = hv; lo[j] = lv; }
+                    for (int j = 0; j < 4; ++j) { elem hv; rem[j] = split_rem(y[j], hv); o[j] = hv; lo[j] = (elem)rem[j]; }
                     ((typename T::vec4*)((elem*)p.out + (size_t)r * p.ldo))[i] = o;
-                    ((typename T::vec4*)((elem*)p.out_lo + (size_t)r * p.ldo))[i] = lo;
+                    if (p.lo_mode == LO_F8) ((uint32_t*)((char*)p.out_lo + (size_t)r * p.ldo * 2))[i] = pack_lo8(rem[0], rem[1], rem[2], rem[3]);
+                    else ((typename T::vec4*)((elem*)p.out_lo + (size_t)r * p.ldo))[i] = lo;
                 } else {
                     typename T::vec4 o = {(elem)y[0], (elem)y[1], (elem)y[2], (elem)y[3]};
                     ((typename T::vec4*)((elem*)p.out + (size_t)r * p.ldo))[i] = o;

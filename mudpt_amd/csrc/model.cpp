@@ -49,6 +49,23 @@ static inline uint16_t f32_to_f16(float f) {
     return u;
 }
 
+// OCP e4m3 (fn: no infinities, maximum 448), round to nearest even, saturating: the weight copies of the e4m3 second pass (common.h LO_F8)
+static inline uint8_t f32_to_e4m3(float f) {
+    const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+    const float a = std::fabs(f);
+    if (!(a == a)) return 0x7f;
+    if (a >= 464.f) return sign | 0x7e;                   // past the midpoint to the (non-existent) next value: the maximum 448
+    if (a <= std::ldexp(1.f, -10)) return sign;           // at most half the smallest subnormal 2^-9: zero (the tie goes to even)
+    int e;
+    (void)std::frexp(a, &e);                              // a = m 2^e, m in [0.5, 1)
+    int E = e - 1 < -6 ? -6 : e - 1;                      // binade (subnormals share 2^-6)
+    float r = std::nearbyint(a / std::ldexp(1.f, E - 3)); // in units of 2^(E - 3): [8, 16) normal, [0, 8) subnormal; RNE (default rounding mode)
+    if (r >= 16.f) { r = 8.f; E += 1; }
+    uint8_t bits = r < 8.f ? (uint8_t)r : (uint8_t)(((E + 7) << 3) | ((int)r - 8));
+    if ((bits & 0x7f) == 0x7f) bits = 0x7e;               // 480 would be the NaN code: saturate
+    return sign | bits;
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -57,7 +74,11 @@ struct DevBuf {
 struct BlockW {
     void *w_in = nullptr, *w_in_t = nullptr, *w_out = nullptr, *w_out_t = nullptr;
     void *w_fc = nullptr, *w_fc_t = nullptr, *w_proj = nullptr, *w_proj_t = nullptr;
-    void *w_in2 = nullptr, *w_out2 = nullptr, *w_fc2 = nullptr, *w_proj2 = nullptr;  // Tower::split: [W | W], rows of 2 x in
+    // e4m3 copies of the four forward weights for the second pass of a LO_F8 split tower (common.h): rows of the T copy's length IN BYTES
+    // (the first `in` bytes used), values W 2^shift with the per-tensor shift that brings max |W| just below 448; s_* = the MX block scale
+    // (E8M0) 2^-shift the matrix instruction applies
+    void *w_in8 = nullptr, *w_out8 = nullptr, *w_fc8 = nullptr, *w_proj8 = nullptr;
+    int s_in8 = 127, s_out8 = 127, s_fc8 = 127, s_proj8 = 127;
     float *b_in = nullptr, *b_out = nullptr, *b_fc = nullptr, *b_proj = nullptr;
     float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
 };
@@ -72,20 +93,25 @@ struct BlockAct {
 struct Tower {
     int d = 0, layers = 0, heads = 0, L = 0, max_seq = 0, Lp = 0;
     bool causal = false;
-    // Split operands (text tower in fp16 mode, the parity configuration): the forward GEMMs' A operands -- both LayerNorm
-    // outputs, the attention output and QuickGELU(u) -- are stored as [hi | lo] with lo = value - hi, and contracted against
-    // [W | W] (K doubled).  Weights are fp16-exact (CLIP checkpoints are fp16-stored), so this removes the 11-bit rounding of
-    // those four operands, which is 87 % of the text-feature error (measured: 6.3e-4 -> 3.1e-4 relative).
-    bool split = false;
+    // Split operands (common.h LoMode).  The forward GEMMs' A operands -- both LayerNorm outputs, the attention output and QuickGELU(u) --
+    // are stored as hi = T(v) plus the remainder lo in a second buffer, and the GEMM contracts lo in a second pass: against the same
+    // weights (LO_F16: 22 bits; CLIP's weights are fp16-exact, checkpoints are fp16-stored) or, as e4m3 bytes, against an e4m3 copy of
+    // the weights on the fp8 matrix pipe (LO_F8: ~15 bits at half the cost of the pass).  Which the modes use, and what each site buys:
+    // DESIGN.md 2 (tests/precision_ablation.py: the text tower needs every bit at every site, the vision tower's error is c_fc / c_proj first).
+    int split = LO_NONE;
+    bool may_split = false;   // low-half buffers (and, vision tower, the e4m3 weights) exist: split / sites / exact_attn are knobs
+    int sites = 0x1f;         // knob: sites that take part -- bit 0 ln_1 -> in_proj, 1 attention -> out_proj, 2 ln_2 -> c_fc, 3 QuickGELU -> c_proj, 4 pixels -> patch embed
+    void *h_lo = nullptr, *g_lo = nullptr, *attn_lo = nullptr;               // low halves of h, g, the attention output: rows of 2 d / 8 d / 2 d bytes
+    void *h_sel_lo = nullptr, *g_sel_lo = nullptr, *attn_sel_lo = nullptr;   // ... of the last block's tail
     int prompt_row0 = 0;  // first prompt row inside a sequence (vision: L - n, text: 1)
     std::vector<BlockW> w;
     std::vector<BlockAct> a;  // layers entries; the last block's output exists on the tail rows only (xout_sel)
     // scratch shared by all blocks
     void *h = nullptr, *g = nullptr;                    // T [M,d], T [M,4d]
-    // Exact mode (mudpt_config.dtype = MUDPT_F32): every forward GEMM runs on split operands (above) and the attention forward in fp32
-    // (attention_exact.hip): in_proj writes q | k | v in fp32 here, the attention kernel leaves the fp16 copy the backward reads.
-    bool exact = false;
-    float* qkv32 = nullptr;                             // fp32 [M, 3d] scratch (exact mode)
+    // Attention forward in fp32 (attention_exact.hip; the parity mode's text tower, knob for its vision tower): in_proj writes q | k | v in
+    // fp32 to qkv32, the attention kernel leaves the fp16 copy the backward reads.
+    bool exact_attn = false;
+    float* qkv32 = nullptr;                             // fp32 [M, 3d] scratch (allocated when may_split && the mode is MUDPT_F32)
     float* dx = nullptr; void* dx_lp = nullptr;         // gradient residual stream fp32 + T copy
     void *dattn = nullptr, *dqkv = nullptr;             // T
     float* delta = nullptr;
@@ -139,7 +165,9 @@ struct mudpt_model {
 
     Tower vis, txt;
     // vision stem / head
-    void* conv_w = nullptr;  // T [dv, 3 p p]   (exact mode: [W | W], rows of 2 K0, against [hi | lo] patch rows)
+    void* conv_w = nullptr;  // T [dv, K0]
+    void* conv_w8 = nullptr; int conv_s8 = 127;  // parity mode: its e4m3 copy (rows of 2 K0 bytes) + block scale, BlockW::w_in8
+    void* patches_lo = nullptr;                  // ... and the low halves of the pixels
     float *cls = nullptr, *vpos = nullptr, *ln_pre_g = nullptr, *ln_pre_b = nullptr, *ln_post_g = nullptr, *ln_post_b = nullptr;
     float* vproj = nullptr;  // [dv, e]
     void* patches = nullptr; // T [B P, 3 p p]
@@ -344,8 +372,7 @@ static int dev_alloc(mudpt_model* m, void** out, size_t bytes) {
     } while (0)
 
 // Frozen weights of a tower (device copies; filled by mudpt_set_weight).
-static int alloc_tower_weights(mudpt_model* m, Tower& t, int d, int layers, int heads, bool causal, int prompt_row0, bool split) {
-    t.split = split;
+static int alloc_tower_weights(mudpt_model* m, Tower& t, int d, int layers, int heads, bool causal, int prompt_row0, bool f8_weights) {
     t.d = d; t.layers = layers; t.heads = heads; t.causal = causal; t.prompt_row0 = prompt_row0;
     t.w.resize(layers);
     t.a.resize(layers);
@@ -355,9 +382,9 @@ static int alloc_tower_weights(mudpt_model* m, Tower& t, int d, int layers, int 
         ALLOC(w.w_out, (size_t)d * d * 2); ALLOC(w.w_out_t, (size_t)d * d * 2);
         ALLOC(w.w_fc, (size_t)4 * d * d * 2); ALLOC(w.w_fc_t, (size_t)4 * d * d * 2);
         ALLOC(w.w_proj, (size_t)4 * d * d * 2); ALLOC(w.w_proj_t, (size_t)4 * d * d * 2);
-        if (split) {
-            ALLOC(w.w_in2, (size_t)3 * d * 2 * d * 2); ALLOC(w.w_out2, (size_t)d * 2 * d * 2);
-            ALLOC(w.w_fc2, (size_t)4 * d * 2 * d * 2); ALLOC(w.w_proj2, (size_t)d * 8 * d * 2);
+        if (f8_weights) {  // e4m3 copies at the T copies' row length in bytes
+            ALLOC(w.w_in8, (size_t)3 * d * d * 2); ALLOC(w.w_out8, (size_t)d * d * 2);
+            ALLOC(w.w_fc8, (size_t)4 * d * d * 2); ALLOC(w.w_proj8, (size_t)d * 4 * d * 2);
         }
         ALLOC(w.b_in, 3 * d * 4); ALLOC(w.b_out, d * 4); ALLOC(w.b_fc, 4 * d * 4); ALLOC(w.b_proj, d * 4);
         ALLOC(w.ln1_g, d * 4); ALLOC(w.ln1_b, d * 4); ALLOC(w.ln2_g, d * 4); ALLOC(w.ln2_b, d * 4);
@@ -367,9 +394,9 @@ static int alloc_tower_weights(mudpt_model* m, Tower& t, int d, int layers, int 
 
 // Bytes of activations + scratch per token row of a tower (what alloc_tower_acts takes per row; sizes the CoCoOp chunk).
 static size_t tower_bytes_per_row(const Tower& t) {
-    const size_t d = t.d, sp = 2;  // split operands counted always (upper bound)
-    const size_t per_layer = d * 4 * 2 + d * 3 * 2 + d * 2 * sp + d * 4 * 2 + 16 + (size_t)t.heads * 4 * 2;
-    const size_t shared = d * 2 * sp + d * 4 * 2 * sp + d * 4 + d * 2 + d * 2 + d * 3 * 2 + d * 4 + (size_t)t.heads * 4 * 2 + (t.exact ? d * 3 * 4 : 0);
+    const size_t d = t.d, sp = 2;  // low halves counted always (upper bound)
+    const size_t per_layer = d * 4 * 2 + d * 3 * 2 + d * 2 + d * 4 * 2 + 16 + (size_t)t.heads * 4 * 2;
+    const size_t shared = d * 2 * sp * 2 + d * 4 * 2 * sp + d * 4 + d * 2 + d * 2 + d * 3 * 2 + d * 4 + (size_t)t.heads * 4 * 2 + d * 3 * 4;
     return per_layer * t.layers + shared;
 }
 
@@ -385,7 +412,6 @@ static int alloc_tower_acts(mudpt_model* m, Tower& t, int L, int max_seq) {
         t.act_allocs.push_back(_p);                                              \
         *(void**)&(ptr) = _p;                                                    \
     } while (0)
-    const size_t sp = t.split ? 2 : 1;
     const int d = t.d, heads = t.heads;
     t.L = L; t.max_seq = max_seq;
     t.Lp = attn_padded_len(L);
@@ -394,18 +420,22 @@ static int alloc_tower_acts(mudpt_model* m, Tower& t, int L, int max_seq) {
         BlockAct& a = t.a[i];
         ALLOC_T(a.x_in, M * d * 4); ALLOC_T(a.x_mid, M * d * 4);
         ALLOC_T(a.mean1, M * 4); ALLOC_T(a.rstd1, M * 4); ALLOC_T(a.mean2, M * 4); ALLOC_T(a.rstd2, M * 4);
-        ALLOC_T(a.qkv, M * 3 * d * 2); ALLOC_T(a.attn, M * d * 2 * sp); ALLOC_T(a.u, M * 4 * d * 2);
+        ALLOC_T(a.qkv, M * 3 * d * 2); ALLOC_T(a.attn, M * d * 2); ALLOC_T(a.u, M * 4 * d * 2);
         ALLOC_T(a.lse, (size_t)max_seq * heads * t.Lp * 4);
     }
-    ALLOC_T(t.h, M * d * 2 * sp); ALLOC_T(t.g, M * 4 * d * 2 * sp);
+    ALLOC_T(t.h, M * d * 2); ALLOC_T(t.g, M * 4 * d * 2);
+    if (t.may_split) {  // the low halves of the split operands: the row length of their T counterparts in bytes, whatever their form
+        ALLOC_T(t.h_lo, M * d * 2); ALLOC_T(t.g_lo, M * 4 * d * 2); ALLOC_T(t.attn_lo, M * d * 2);
+    }
     ALLOC_T(t.dx, M * d * 4); ALLOC_T(t.dx_lp, M * d * 2);
     ALLOC_T(t.dattn, M * d * 2); ALLOC_T(t.dqkv, M * 3 * d * 2);
     ALLOC_T(t.delta, (size_t)max_seq * heads * t.Lp * 4);
     ALLOC_T(t.upd, M * d * 4);
-    if (t.exact) ALLOC_T(t.qkv32, M * 3 * d * 4);
+    if (t.may_split && m->exact) ALLOC_T(t.qkv32, M * 3 * d * 4);
     const size_t S = (size_t)max_seq;
     ALLOC_T(t.xin_sel, S * d * 4); ALLOC_T(t.xmid_sel, S * d * 4); ALLOC_T(t.xout_sel, S * d * 4);
-    ALLOC_T(t.attn_sel, S * d * 2 * sp); ALLOC_T(t.h_sel, S * d * 2 * sp); ALLOC_T(t.u_sel, S * 4 * d * 2); ALLOC_T(t.g_sel, S * 4 * d * 2 * sp); ALLOC_T(t.dattn_sel, S * d * 2);
+    ALLOC_T(t.attn_sel, S * d * 2); ALLOC_T(t.h_sel, S * d * 2); ALLOC_T(t.u_sel, S * 4 * d * 2); ALLOC_T(t.g_sel, S * 4 * d * 2); ALLOC_T(t.dattn_sel, S * d * 2);
+    if (t.may_split) { ALLOC_T(t.attn_sel_lo, S * d * 2); ALLOC_T(t.h_sel_lo, S * d * 2); ALLOC_T(t.g_sel_lo, S * 4 * d * 2); }
     ALLOC_T(t.dsel, S * d * 4); ALLOC_T(t.dsel_lp, S * d * 2);
     ALLOC_T(t.q_sel, S * d * 2); ALLOC_T(t.dq_sel, S * d * 2); ALLOC_T(t.dqx_sel, S * d * 2); ALLOC_T(t.lse_sel, S * heads * 4);
     t.head_n = m->cfg.n_ctx;
@@ -443,12 +473,21 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
 
     mudpt_model* m = new mudpt_model();
     m->cfg = *c;
-    // MUDPT_F32 ("exact"): the kernels' operand type is fp16, every forward operand a [hi | lo] pair (22 bits), attention forward in fp32
+    // MUDPT_F32 (the parity mode): the kernels' operand type is fp16.  Text tower: every forward GEMM operand a 22-bit
+    // (hi, lo) pair and the attention forward in fp32 -- each of its rounding sites alone costs 2.5e-3 on the logits at logit scale 100.
+    // Vision tower: every forward GEMM operand (and the pixels) hi + an e4m3 remainder contracted on the fp8 matrix pipe, attention in
+    // fp16.  Knobs vis_lo / vis_exact_attn / vis_sites / txt_sites select the other points of the ablation (vis_lo = 1, vis_exact_attn = 1:
+    // round 3's "exact" mode).  MUDPT_F16 splits the text tower's GEMM operands only (the round-2 mode, kept as it was).
     m->exact = c->dtype == MUDPT_F32;
     m->dtype = m->exact ? (int)MUDPT_F16 : c->dtype;
-    m->vis.exact = m->txt.exact = m->exact;
-    if (m->exact) m->last_single = false;  // the single-query kernels of the last block take fp16 q, k, v: the general (exact) forward runs instead
-    m->lp_grad = (c->dtype == MUDPT_BF16);
+    m->vis.may_split = m->exact;
+    m->txt.may_split = m->dtype == MUDPT_F16;
+    m->vis.split = m->exact ? LO_F8 : LO_NONE;
+    m->txt.split = m->txt.may_split ? LO_F16 : LO_NONE;
+    m->txt.exact_attn = m->exact;
+    // the gradient of the residual stream in T: bf16 mode, and the parity mode (its bound is on the LOGITS; its backward is the fp16 mode's
+    // with fp16 activation gradients, as the reference's own fp16 model has them: gradient errors +30 %, -0.9 ms per step; knob lp_grad = 0)
+    m->lp_grad = (c->dtype == MUDPT_BF16 || c->dtype == MUDPT_F32);
     m->lp_upd = (c->dtype == MUDPT_BF16);
     m->cocoop = cocoop;
     m->ct = c->n_cls;
@@ -456,20 +495,20 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     const int dv = c->v_width, dt = c->t_width, e = c->embed_dim, n = c->n_ctx, D1 = m->cfg.depth - 1, B = c->max_batch, C = c->n_cls;
     const int TS = cocoop ? B * C : C;  // text sequences per step: one per (image, class) pair in CoCoOp (trainers/cocoop.py:187-194)
     auto fail = [&](int code) { mudpt_destroy(m); return code; };
-    if (int r = alloc_tower_weights(m, m->vis, dv, c->v_layers, c->v_heads, false, cocoop ? Lv : Lv - n, m->exact)) return fail(r);
+    if (int r = alloc_tower_weights(m, m->vis, dv, c->v_layers, c->v_heads, false, cocoop ? Lv : Lv - n, m->exact)) return fail(r);  // e4m3 weight copies: vision tower of the parity mode
     if (int r = alloc_tower_acts(m, m->vis, Lv, B)) return fail(r);
     // the text tower's activations are sized by mudpt_set_class_prompts: its trimmed length (max(eot) + 1 of ctx_len positions) and, for
     // CoCoOp, the number of images whose B * C prompts fit the memory budget at once are only known there
-    if (int r = alloc_tower_weights(m, m->txt, dt, c->t_layers, c->t_heads, true, 1, m->dtype == MUDPT_F16)) return fail(r);
+    if (int r = alloc_tower_weights(m, m->txt, dt, c->t_layers, c->t_heads, true, 1, false)) return fail(r);
     m->txt.L = c->ctx_len; m->txt.Lp = attn_padded_len(c->ctx_len);
     auto body = [&]() -> int {
         const int K0 = (3 * c->patch * c->patch + 63) / 64 * 64;  // conv-as-GEMM K, zero-padded to the GEMM's granularity (ViT-L/14: 588 -> 640)
-        const size_t xs = m->exact ? 2 : 1;  // exact mode: [hi | lo] patch rows against [W | W]
-        ALLOC(m->conv_w, (size_t)dv * K0 * 2 * xs);
+        ALLOC(m->conv_w, (size_t)dv * K0 * 2);
+        if (m->exact) { ALLOC(m->conv_w8, (size_t)dv * K0 * 2); ALLOC(m->patches_lo, (size_t)B * P * K0 * 2); }  // split pixels (vision tower's site 4)
         ALLOC(m->cls, dv * 4); ALLOC(m->vpos, (size_t)(1 + P) * dv * 4);
         ALLOC(m->ln_pre_g, dv * 4); ALLOC(m->ln_pre_b, dv * 4); ALLOC(m->ln_post_g, dv * 4); ALLOC(m->ln_post_b, dv * 4);
         ALLOC(m->vproj, (size_t)dv * e * 4);
-        ALLOC(m->patches, (size_t)B * P * K0 * 2 * xs);
+        ALLOC(m->patches, (size_t)B * P * K0 * 2);
         ALLOC(m->xpre, (size_t)B * Lv * dv * 4); ALLOC(m->pre_mean, (size_t)B * Lv * 4); ALLOC(m->pre_rstd, (size_t)B * Lv * 4);
         ALLOC(m->f_ln, (size_t)B * dv * 4); ALLOC(m->post_mean, B * 4); ALLOC(m->post_rstd, B * 4); ALLOC(m->df_ln, (size_t)B * dv * 4);
         ALLOC(m->cls_rows, B * 4); ALLOC(m->vprompt_rows, (size_t)B * n * 4);
@@ -566,13 +605,22 @@ static int upload_lp(int dtype, void* dst, void* dst_t, const float* src, size_t
     return MUDPT_OK;
 }
 
-// W [rows, cols] fp32 host -> T device [rows, 2 cols] = [W | W]: the B operand of a split-operand GEMM
-static int upload_lp_dup(int dtype, void* dst, const float* src, size_t rows, size_t cols) {
-    std::vector<uint16_t> tmp(rows * 2 * cols);
-    auto cv = [&](float f) { return dtype == DT_BF16 ? f32_to_bf16(f) : f32_to_f16(f); };
+// W [rows, cols] fp32 host -> e4m3 device copy for the second pass of a LO_F8 split GEMM: rows of 2 * cols BYTES (the T copy's row length, so
+// that byte offsets into W and W8 agree), the first cols of them W 2^shift in e4m3; *scale_e8m0 = the block scale 2^-shift for the MFMA
+static int upload_e4m3(void* dst, int* scale_e8m0, const float* src, size_t rows, size_t cols) {
+    float mx = 0.f;
+    for (size_t i = 0; i < rows * cols; ++i) mx = std::max(mx, std::fabs(src[i]));
+    int shift = 0;
+    if (mx > 0.f && std::isfinite(mx)) {
+        shift = (int)std::floor(std::log2(448.f / mx));
+        while (std::ldexp(mx, shift) > 448.f) --shift;
+        shift = std::max(-100, std::min(100, shift));
+    }
+    std::vector<uint8_t> tmp(rows * 2 * cols, 0);
     for (size_t r = 0; r < rows; ++r)
-        for (size_t c = 0; c < cols; ++c) tmp[r * 2 * cols + c] = tmp[r * 2 * cols + cols + c] = cv(src[r * cols + c]);
-    HIP_TRY(hipMemcpy(dst, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+        for (size_t c = 0; c < cols; ++c) tmp[r * 2 * cols + c] = f32_to_e4m3(std::ldexp(src[r * cols + c], shift));
+    HIP_TRY(hipMemcpy(dst, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+    *scale_e8m0 = 127 - shift;
     return MUDPT_OK;
 }
 
@@ -589,13 +637,13 @@ static int set_block_weight(mudpt_model* m, Tower& t, int layer, const std::stri
             ARG_CHECK(numel == f.sz, "set_weight: %s expects %zu elements, got %zu", f.n, f.sz, numel);
             return upload_f32(f.p, data, numel);
         }
-    struct LP { const char* n; void* p; void* pt; void* p2; size_t rows, cols; };
-    const LP lps[] = {{"attn.in_proj_weight", w.w_in, w.w_in_t, w.w_in2, 3 * d, d}, {"attn.out_proj.weight", w.w_out, w.w_out_t, w.w_out2, d, d},
-                      {"mlp.c_fc.weight", w.w_fc, w.w_fc_t, w.w_fc2, 4 * d, d}, {"mlp.c_proj.weight", w.w_proj, w.w_proj_t, w.w_proj2, d, 4 * d}};
+    struct LP { const char* n; void* p; void* pt; void* p8; int* s8; size_t rows, cols; };
+    const LP lps[] = {{"attn.in_proj_weight", w.w_in, w.w_in_t, w.w_in8, &w.s_in8, 3 * d, d}, {"attn.out_proj.weight", w.w_out, w.w_out_t, w.w_out8, &w.s_out8, d, d},
+                      {"mlp.c_fc.weight", w.w_fc, w.w_fc_t, w.w_fc8, &w.s_fc8, 4 * d, d}, {"mlp.c_proj.weight", w.w_proj, w.w_proj_t, w.w_proj8, &w.s_proj8, d, 4 * d}};
     for (const LP& l : lps)
         if (name == l.n) {
             ARG_CHECK(numel == l.rows * l.cols, "set_weight: %s expects %zu elements, got %zu", l.n, l.rows * l.cols, numel);
-            if (t.split) { if (int rc = upload_lp_dup(m->dtype, l.p2, data, l.rows, l.cols)) return rc; }
+            if (l.p8) { if (int rc = upload_e4m3(l.p8, l.s8, data, l.rows, l.cols)) return rc; }
             return upload_lp(m->dtype, l.p, l.pt, data, l.rows, l.cols);
         }
     set_error("set_weight: unknown block tensor '%s'", name.c_str());
@@ -623,7 +671,8 @@ extern "C" int mudpt_set_weight(mudpt_model* m, const char* key, const float* da
         const size_t k0 = (size_t)3 * c.patch * c.patch, k0p = (k0 + 63) / 64 * 64;
         std::vector<float> padded(dv * k0p, 0.f);  // rows zero-padded like the im2col rows
         for (size_t r = 0; r < dv; ++r) memcpy(&padded[r * k0p], data + r * k0, k0 * 4);
-        rc = m->exact ? upload_lp_dup(m->dtype, m->conv_w, padded.data(), dv, k0p) : upload_lp(m->dtype, m->conv_w, nullptr, padded.data(), dv, k0p);
+        rc = upload_lp(m->dtype, m->conv_w, nullptr, padded.data(), dv, k0p);
+        if (!rc && m->conv_w8) rc = upload_e4m3(m->conv_w8, &m->conv_s8, padded.data(), dv, k0p);
     }
     else if (k == "visual.class_embedding") { EXPECT(dv); rc = upload_f32(m->cls, data, numel); }
     else if (k == "visual.positional_embedding") { EXPECT((1 + P) * dv); rc = upload_f32(m->vpos, data, numel); }
@@ -837,27 +886,48 @@ static int ready(mudpt_model* m, int B, bool need_grads) {
     return MUDPT_OK;
 }
 
+// Split operands: the form of the low half at GEMM site `site` of tower t whose contraction length is K (common.h LoMode) -- what the
+// producing kernel writes and what the consuming GEMM's second pass reads.  The e4m3 pass needs K % 128 == 0 (one matrix instruction
+// contracts 128 k): narrower sites of a LO_F8 tower (the 192-wide test shapes) fall back to the fp16 pair.
+enum Site : int { SITE_QKV = 0, SITE_OUT = 1, SITE_FC = 2, SITE_PROJ = 3, SITE_PATCH = 4 };
+static int site_mode(const Tower& t, int site, int K) {
+    if (t.split == LO_NONE || !((t.sites >> site) & 1)) return LO_NONE;
+    return (t.split == LO_F8 && K % 128 == 0) ? LO_F8 : LO_F16;
+}
+// ... and the second-pass fields of the consuming GEMM: the low half of A, and for the e4m3 form the e4m3 weights (same row offset as B) + scale
+static void split_operand(GemmArgs& g, int mode, const void* A_lo, const void* B8, int b8_scale) {
+    if (mode == LO_NONE) return;
+    g.A_lo = A_lo; g.lo_mode = mode;
+    if (mode == LO_F8) { g.B8 = B8; g.b8_scale = b8_scale; }
+}
+
 // Forward of the last block after its attention, on the one used row of every sequence (Tower::tail_rows): gathers the
 // rows, then out_proj (+ residual in the small GEMM's epilogue), ln_2, c_fc + QuickGELU, c_proj (+ residual) -> t.xout_sel.
 static int block_fwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s, bool attn_sel_ready = false) {
     const int i = t.layers - 1, S = nseq, d = t.d, dt = m->dtype;
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
-    const int sp = t.split ? 2 : 1;  // [hi | lo] operands: rows of sp * d (sp * 4 d) elements, K doubled, B = [W | W]
     const size_t esz = 2;
-    if (!attn_sel_ready) TRY(launch_gather_rows(a.attn, (size_t)sp * d * esz, t.tail_rows, t.attn_sel, (size_t)sp * d * esz, S, sp * d * (int)esz, s));
+    const int m_out = site_mode(t, SITE_OUT, d), m_fc = site_mode(t, SITE_FC, d), m_proj = site_mode(t, SITE_PROJ, 4 * d);
+    if (!attn_sel_ready) {
+        TRY(launch_gather_rows(a.attn, (size_t)d * esz, t.tail_rows, t.attn_sel, (size_t)d * esz, S, d * (int)esz, s));
+        if (m_out != LO_NONE) TRY(launch_gather_rows(t.attn_lo, (size_t)d * esz, t.tail_rows, t.attn_sel_lo, (size_t)d * esz, S, d * (int)esz, s));
+    }
     TRY(launch_gather_rows(a.x_in, (size_t)d * 4, t.tail_rows, t.xin_sel, (size_t)d * 4, S, d * 4, s));
-    GemmArgs o; o.A = t.attn_sel; o.lda = sp * d; o.B = t.split ? w.w_out2 : w.w_out; o.ldb = sp * d; o.M = S; o.N = d; o.K = sp * d; o.bias = w.b_out;
+    GemmArgs o; o.A = t.attn_sel; o.lda = d; o.B = w.w_out; o.ldb = d; o.M = S; o.N = d; o.K = d; o.bias = w.b_out;
+    split_operand(o, m_out, t.attn_sel_lo, w.w_out8, w.s_out8);
     o.out0 = t.xmid_sel; o.ldo0 = d; o.aux = t.xin_sel; o.ldaux = d;
     TRY(gemm_call(m, EPI_RESIDUAL, o, s));
-    LnFwdArgs l2; l2.x = t.xmid_sel; l2.ldx = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h_sel; l2.ldo = sp * d; l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = S; l2.d = d;
-    if (t.split) l2.out_lo = (char*)t.h_sel + (size_t)d * esz;
+    LnFwdArgs l2; l2.x = t.xmid_sel; l2.ldx = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h_sel; l2.ldo = d; l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = S; l2.d = d;
+    if (m_fc != LO_NONE) { l2.out_lo = t.h_sel_lo; l2.lo_mode = m_fc; }
     TRY(launch_ln_fwd(dt, l2, s));
-    GemmArgs f; f.A = t.h_sel; f.lda = sp * d; f.B = t.split ? w.w_fc2 : w.w_fc; f.ldb = sp * d; f.M = S; f.N = 4 * d; f.K = sp * d; f.bias = w.b_fc;
-    f.out0 = t.u_sel; f.ldo0 = 4 * d; f.out1 = t.g_sel; f.ldo1 = sp * 4 * d;
-    if (t.split) f.out1_lo = (char*)t.g_sel + (size_t)4 * d * esz;
+    GemmArgs f; f.A = t.h_sel; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = S; f.N = 4 * d; f.K = d; f.bias = w.b_fc;
+    split_operand(f, m_fc, t.h_sel_lo, w.w_fc8, w.s_fc8);
+    f.out0 = t.u_sel; f.ldo0 = 4 * d; f.out1 = t.g_sel; f.ldo1 = 4 * d;
+    if (m_proj != LO_NONE) { f.out1_lo = t.g_sel_lo; f.out1_lo_mode = m_proj; }
     TRY(gemm_call(m, EPI_GELU, f, s));
-    GemmArgs p; p.A = t.g_sel; p.lda = sp * 4 * d; p.B = t.split ? w.w_proj2 : w.w_proj; p.ldb = sp * 4 * d; p.M = S; p.N = d; p.K = sp * 4 * d; p.bias = w.b_proj;
+    GemmArgs p; p.A = t.g_sel; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = S; p.N = d; p.K = 4 * d; p.bias = w.b_proj;
+    split_operand(p, m_proj, t.g_sel_lo, w.w_proj8, w.s_proj8);
     p.out0 = t.xout_sel; p.ldo0 = d; p.aux = t.xmid_sel; p.ldaux = d;
     TRY(gemm_call(m, EPI_RESIDUAL, p, s));
     return MUDPT_OK;
@@ -876,10 +946,11 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
     const bool lp = m->lp_upd;
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
-    const int sp = t.split ? 2 : 1;  // split operands (Tower::split): [hi | lo] rows, K doubled, B = [W | W]
     const size_t esz = 2;
-    LnFwdArgs l1; l1.x = a.x_in; l1.ldx = d; l1.gamma = w.ln1_g; l1.beta = w.ln1_b; l1.out = t.h; l1.ldo = sp * d; l1.mean = a.mean1; l1.rstd = a.rstd1; l1.rows = M; l1.d = d;
-    if (t.split) l1.out_lo = (char*)t.h + (size_t)d * esz;
+    // split operands (Tower::split): the form of each site's low half (LO_NONE: the site runs on T alone)
+    const int m_qkv = site_mode(t, SITE_QKV, d), m_out = site_mode(t, SITE_OUT, d), m_fc = site_mode(t, SITE_FC, d), m_proj = site_mode(t, SITE_PROJ, 4 * d);
+    LnFwdArgs l1; l1.x = a.x_in; l1.ldx = d; l1.gamma = w.ln1_g; l1.beta = w.ln1_b; l1.out = t.h; l1.ldo = d; l1.mean = a.mean1; l1.rstd = a.rstd1; l1.rows = M; l1.d = d;
+    if (m_qkv != LO_NONE) { l1.out_lo = t.h_lo; l1.lo_mode = m_qkv; }
     if (i > 0) {
         l1.x = t.a[i - 1].x_mid; l1.ldadd = d; l1.xout = a.x_in; l1.ldxout = d;
         if (lp) l1.add_lp = t.upd; else l1.add = t.upd;
@@ -901,50 +972,57 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
     } else {
         TRY(ln_fwd_call(m, t, l1, s));
     }
-    if (i + 1 == t.layers && m->last_single && t.tail_rows) {
+    if (i + 1 == t.layers && m->last_single && !t.exact_attn && t.tail_rows) {
         // Last block: only ONE query per sequence is ever used (CLS / EOT row).  K and V for every row (the k, v thirds of in_proj: rows
         // d .. 3d of its weight, written into the k, v thirds of the packed qkv buffer), q for the selected rows only, single-query attention
-        // straight into the compact attn_sel the tail works on.
-        const char* wkv = (const char*)(t.split ? w.w_in2 : w.w_in) + (size_t)d * sp * d * esz;
-        GemmArgs kv; kv.A = t.h; kv.lda = sp * d; kv.B = wkv; kv.ldb = sp * d; kv.M = M; kv.N = 2 * d; kv.K = sp * d; kv.bias = w.b_in + d;
+        // straight into the compact attn_sel the tail works on.  (With the fp32 attention forward the general kernel runs instead: the
+        // single-query kernels take fp16 q, k, v.)
+        GemmArgs kv; kv.A = t.h; kv.lda = d; kv.B = (const char*)w.w_in + (size_t)d * d * esz; kv.ldb = d; kv.M = M; kv.N = 2 * d; kv.K = d; kv.bias = w.b_in + d;
+        split_operand(kv, m_qkv, t.h_lo, w.w_in8 ? (const char*)w.w_in8 + (size_t)d * d * esz : nullptr, w.s_in8);
         kv.out0 = (char*)a.qkv + (size_t)d * esz; kv.ldo0 = 3 * d;
         TRY(gemm_call(m, EPI_STORE, kv, s));
-        TRY(launch_gather_rows(t.h, (size_t)sp * d * esz, t.tail_rows, t.h_sel, (size_t)sp * d * esz, nseq, sp * d * (int)esz, s));
-        GemmArgs qs; qs.A = t.h_sel; qs.lda = sp * d; qs.B = t.split ? w.w_in2 : w.w_in; qs.ldb = sp * d; qs.M = nseq; qs.N = d; qs.K = sp * d; qs.bias = w.b_in;
+        TRY(launch_gather_rows(t.h, (size_t)d * esz, t.tail_rows, t.h_sel, (size_t)d * esz, nseq, d * (int)esz, s));
+        if (m_qkv != LO_NONE) TRY(launch_gather_rows(t.h_lo, (size_t)d * esz, t.tail_rows, t.h_sel_lo, (size_t)d * esz, nseq, d * (int)esz, s));
+        GemmArgs qs; qs.A = t.h_sel; qs.lda = d; qs.B = w.w_in; qs.ldb = d; qs.M = nseq; qs.N = d; qs.K = d; qs.bias = w.b_in;
+        split_operand(qs, m_qkv, t.h_sel_lo, w.w_in8, w.s_in8);
         qs.out0 = t.q_sel; qs.ldo0 = d;
         TRY(gemm_call(m, EPI_STORE, qs, s));
         for (const Tower::Seg& g : segs) {
             AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
             at.sel_rows = segs.size() > 1 ? t.tail_local + g.seq0 : t.tail_rows;
-            char* osel = (char*)t.attn_sel + (size_t)g.seq0 * sp * d * esz;
-            TRY(launch_attn_fwd_single(dt, at, (const char*)t.q_sel + (size_t)g.seq0 * d * esz, osel, t.split ? osel + (size_t)d * esz : nullptr, sp * d,
-                                       t.lse_sel + (size_t)g.seq0 * t.heads, s));
+            at.lo_mode = m_out;
+            TRY(launch_attn_fwd_single(dt, at, (const char*)t.q_sel + (size_t)g.seq0 * d * esz, (char*)t.attn_sel + (size_t)g.seq0 * d * esz,
+                                       m_out != LO_NONE ? (char*)t.attn_sel_lo + (size_t)g.seq0 * d * esz : nullptr, d, t.lse_sel + (size_t)g.seq0 * t.heads, s));
         }
         return block_fwd_tail(m, t, nseq, s, true);
     }
-    GemmArgs q; q.A = t.h; q.lda = sp * d; q.B = t.split ? w.w_in2 : w.w_in; q.ldb = sp * d; q.M = M; q.N = 3 * d; q.K = sp * d; q.bias = w.b_in; q.out0 = a.qkv; q.ldo0 = 3 * d;
-    if (t.exact) q.out0 = t.qkv32;  // fp32 q | k | v for the exact attention forward, which leaves their fp16 copy in a.qkv for the backward
-    TRY(gemm_call(m, t.exact ? EPI_STORE_F32 : EPI_STORE, q, s));
+    GemmArgs q; q.A = t.h; q.lda = d; q.B = w.w_in; q.ldb = d; q.M = M; q.N = 3 * d; q.K = d; q.bias = w.b_in; q.out0 = a.qkv; q.ldo0 = 3 * d;
+    split_operand(q, m_qkv, t.h_lo, w.w_in8, w.s_in8);
+    if (t.exact_attn) q.out0 = t.qkv32;  // fp32 q | k | v for the fp32 attention forward, which leaves their fp16 copy in a.qkv for the backward
+    TRY(gemm_call(m, t.exact_attn ? EPI_STORE_F32 : EPI_STORE, q, s));
     for (const Tower::Seg& g : segs) {
-        AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * sp * d * esz; at.lse = a.lse + g.lse0;
+        AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * d * esz; at.lse = a.lse + g.lse0;
         at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
-        if (t.split) { at.ld_out = 2 * d; at.out_lo = (char*)at.out + (size_t)d * esz; }
-        if (t.exact) { at.qkv32 = t.qkv32 + (size_t)g.row0 * 3 * d; at.qkv_lp = (char*)a.qkv + (size_t)g.row0 * 3 * d * esz; }
+        if (m_out != LO_NONE) { at.out_lo = (char*)t.attn_lo + (size_t)g.row0 * d * esz; at.lo_mode = m_out; }
+        if (t.exact_attn) { at.qkv32 = t.qkv32 + (size_t)g.row0 * 3 * d; at.qkv_lp = (char*)a.qkv + (size_t)g.row0 * 3 * d * esz; }
         TRY(attn_call(m, t, at, false, s));
     }
     if (i + 1 == t.layers) return block_fwd_tail(m, t, nseq, s);
-    GemmArgs o; o.A = a.attn; o.lda = sp * d; o.B = t.split ? w.w_out2 : w.w_out; o.ldb = sp * d; o.M = M; o.N = d; o.K = sp * d; o.bias = w.b_out; o.out0 = t.upd; o.ldo0 = d;
-    const bool fs = !t.causal && !t.exact;  // forward split K: the vision tower's out_proj / c_proj at tiny batches only (gemm_call)
+    GemmArgs o; o.A = a.attn; o.lda = d; o.B = w.w_out; o.ldb = d; o.M = M; o.N = d; o.K = d; o.bias = w.b_out; o.out0 = t.upd; o.ldo0 = d;
+    split_operand(o, m_out, t.attn_lo, w.w_out8, w.s_out8);
+    const bool fs = !t.causal && t.split == LO_NONE;  // forward split K: the vision tower's out_proj / c_proj at tiny batches only (gemm_call), never with split operands
     TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, o, s, false, fs));
-    LnFwdArgs l2; l2.x = a.x_in; l2.ldx = d; if (lp) l2.add_lp = t.upd; else l2.add = t.upd; l2.ldadd = d; l2.xout = a.x_mid; l2.ldxout = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = sp * d;
-    if (t.split) l2.out_lo = (char*)t.h + (size_t)d * esz;
+    LnFwdArgs l2; l2.x = a.x_in; l2.ldx = d; if (lp) l2.add_lp = t.upd; else l2.add = t.upd; l2.ldadd = d; l2.xout = a.x_mid; l2.ldxout = d; l2.gamma = w.ln2_g; l2.beta = w.ln2_b; l2.out = t.h; l2.ldo = d;
+    if (m_fc != LO_NONE) { l2.out_lo = t.h_lo; l2.lo_mode = m_fc; }
     l2.mean = a.mean2; l2.rstd = a.rstd2; l2.rows = M; l2.d = d;
     TRY(ln_fwd_call(m, t, l2, s));
-    GemmArgs f; f.A = t.h; f.lda = sp * d; f.B = t.split ? w.w_fc2 : w.w_fc; f.ldb = sp * d; f.M = M; f.N = 4 * d; f.K = sp * d; f.bias = w.b_fc; f.out0 = a.u; f.ldo0 = 4 * d;
-    f.out1 = t.g; f.ldo1 = sp * 4 * d;
-    if (t.split) f.out1_lo = (char*)t.g + (size_t)4 * d * esz;
+    GemmArgs f; f.A = t.h; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = M; f.N = 4 * d; f.K = d; f.bias = w.b_fc; f.out0 = a.u; f.ldo0 = 4 * d;
+    split_operand(f, m_fc, t.h_lo, w.w_fc8, w.s_fc8);
+    f.out1 = t.g; f.ldo1 = 4 * d;
+    if (m_proj != LO_NONE) { f.out1_lo = t.g_lo; f.out1_lo_mode = m_proj; }
     TRY(gemm_call(m, EPI_GELU, f, s));
-    GemmArgs p; p.A = t.g; p.lda = sp * 4 * d; p.B = t.split ? w.w_proj2 : w.w_proj; p.ldb = sp * 4 * d; p.M = M; p.N = d; p.K = sp * 4 * d; p.bias = w.b_proj; p.out0 = t.upd; p.ldo0 = d;
+    GemmArgs p; p.A = t.g; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = M; p.N = d; p.K = 4 * d; p.bias = w.b_proj; p.out0 = t.upd; p.ldo0 = d;
+    split_operand(p, m_proj, t.g_lo, w.w_proj8, w.s_proj8);
     TRY(gemm_call(m, lp ? EPI_STORE : EPI_STORE_F32, p, s, false, fs));
     return MUDPT_OK;
 }
@@ -967,14 +1045,13 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     TRY(launch_ln_bwd(dt, b2, s));  // t.dsel(_lp) = gradient w.r.t. x_mid on the selected rows
     GemmArgs g3; g3.A = t.dsel_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = S; g3.N = d; g3.K = d; g3.out0 = t.dattn_sel; g3.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g3, s, !t.causal));
-    if (m->last_single) {
+    if (m->last_single && !t.exact_attn) {
         // single-query attention backward: dK, dV of every row (k, v thirds of t.dqkv) and dq of the one query per sequence
-        const int spd = (t.split ? 2 : 1) * d;
         for (const Tower::Seg& g : segs) {
             AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.dqkv = (char*)t.dqkv + (size_t)g.row0 * 3 * d * esz;
             at.sel_rows = segs.size() > 1 ? t.tail_local + g.seq0 : t.tail_rows;
             at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
-            TRY(launch_attn_bwd_single(dt, at, (const char*)t.q_sel + (size_t)g.seq0 * d * esz, (const char*)t.attn_sel + (size_t)g.seq0 * spd * esz, spd,
+            TRY(launch_attn_bwd_single(dt, at, (const char*)t.q_sel + (size_t)g.seq0 * d * esz, (const char*)t.attn_sel + (size_t)g.seq0 * d * esz, d,
                                        (const char*)t.dattn_sel + (size_t)g.seq0 * d * esz, t.lse_sel + (size_t)g.seq0 * t.heads,
                                        (char*)t.dq_sel + (size_t)g.seq0 * d * esz, s));
         }
@@ -990,11 +1067,9 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(t.dattn, 0, (size_t)M * d * esz, s));
     TRY(launch_scatter_rows(t.dattn_sel, (size_t)d * esz, t.tail_rows, t.dattn, (size_t)d * esz, S, d * (int)esz, s));
     for (const Tower::Seg& g : segs) {
-        const int spd = (t.split ? 2 : 1) * d;
-        AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * spd * esz; at.lse = a.lse + g.lse0;
+        AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * d * esz; at.lse = a.lse + g.lse0;
         at.dout = (const char*)t.dattn + (size_t)g.row0 * d * esz; at.dqkv = (char*)t.dqkv + (size_t)g.row0 * 3 * d * esz; at.delta = t.delta + g.lse0;
         at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
-        if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
         at.sel_rows = segs.size() > 1 ? t.tail_local + g.seq0 : t.tail_rows;  // d(attention output) is zero except on those rows: the kernels skip the all-zero query blocks
         TRY(attn_call(m, t, at, true, s));
     }
@@ -1033,11 +1108,10 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s, f
     GemmArgs g3; g3.A = t.dx_lp; g3.lda = d; g3.B = w.w_out_t; g3.ldb = d; g3.M = M; g3.N = d; g3.K = d; g3.out0 = t.dattn; g3.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g3, s, !t.causal));
     for (const Tower::Seg& g : tower_segs(t, nseq)) {
-        const size_t esz = 2, spd = (size_t)(t.split ? 2 : 1) * d;
-        AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * spd * esz; at.lse = a.lse + g.lse0;
+        const size_t esz = 2;
+        AttnArgs at; at.qkv = (const char*)a.qkv + (size_t)g.row0 * 3 * d * esz; at.out = (char*)a.attn + (size_t)g.row0 * d * esz; at.lse = a.lse + g.lse0;
         at.dout = (const char*)t.dattn + (size_t)g.row0 * d * esz; at.dqkv = (char*)t.dqkv + (size_t)g.row0 * 3 * d * esz; at.delta = t.delta + g.lse0;
         at.B = g.nseq; at.L = g.L; at.H = t.heads; at.causal = t.causal;
-        if (t.split) at.ld_out = 2 * d;  // the forward output's hi half sits in [hi | lo] rows
         // block 0: only the prompt rows of dqkv are read below (Tower::head_rows)
         if (i == 0 && t.head_rows && t.layers > 1 && m->attn_window) { at.win_row0 = t.prompt_row0; at.win_n = t.head_n; }
         TRY(attn_call(m, t, at, true, s));
@@ -1073,10 +1147,11 @@ static int vision_forward(mudpt_model* m, const float* images, int B, hipStream_
     const int dv = c.v_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1;
     const int P = (c.image_size / c.patch) * (c.image_size / c.patch), Lv = m->vis.L, K0 = (3 * c.patch * c.patch + 63) / 64 * 64;
     float* Pm = m->params;
-    const int xs = m->exact ? 2 : 1;  // exact mode: pixels as [hi | lo] pairs (an fp16 pixel alone carries 2.4e-4 of rounding into block 0)
-    if (m->exact) TRY(launch_patchify_split(m->dtype, images, m->patches, B, c.image_size, c.patch, K0, s));
+    const int m_patch = site_mode(m->vis, SITE_PATCH, K0);  // parity mode: split pixels (an fp16 pixel alone carries 2.4e-4 of rounding into block 0)
+    if (m_patch != LO_NONE) TRY(launch_patchify_split(m->dtype, images, m->patches, m->patches_lo, m_patch, B, c.image_size, c.patch, K0, s));
     else TRY(launch_patchify(m->dtype, images, m->patches, B, c.image_size, c.patch, K0, s));
-    GemmArgs pe; pe.A = m->patches; pe.lda = xs * K0; pe.B = m->conv_w; pe.ldb = xs * K0; pe.M = B * P; pe.N = dv; pe.K = xs * K0; pe.out0 = m->xpre; pe.ldo0 = dv;
+    GemmArgs pe; pe.A = m->patches; pe.lda = K0; pe.B = m->conv_w; pe.ldb = K0; pe.M = B * P; pe.N = dv; pe.K = K0; pe.out0 = m->xpre; pe.ldo0 = dv;
+    split_operand(pe, m_patch, m->patches_lo, m->conv_w8, m->conv_s8);
     pe.patches = P; pe.seq_len = Lv; pe.pos = m->vpos;
     TRY(gemm_call(m, EPI_PATCH, pe, s));
     TRY(launch_set_rows(m->xpre, B, Lv, dv, 0, 1, m->cls, m->vpos, s));
@@ -1562,15 +1637,35 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
     if (!strcmp(name, "attn_fused_w1")) { m->attn_fused_w1 = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "split_k")) { m->split_k = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "attn_window")) { m->attn_window = value != 0; return MUDPT_OK; }
-    if (!strcmp(name, "last_single")) { m->last_single = value != 0 && !m->exact; return MUDPT_OK; }
+    if (!strcmp(name, "last_single")) { m->last_single = value != 0; return MUDPT_OK; }  // (a tower with the fp32 attention forward runs the general kernels anyway)
     if (!strcmp(name, "txt_bucket_cost")) { m->txt_bucket_cost = value > 0 ? value : 0; m->prompts_set = false; return MUDPT_OK; }
     if (!strcmp(name, "txt_buckets")) { m->txt_buckets = value > 1 ? value : 1; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
     if (!strcmp(name, "prof_stride")) { m->prof_stride = value > 1 ? value : 1; return MUDPT_OK; }
     if (!strcmp(name, "cocoop_chunk")) { m->cocoop_chunk = value; m->prompts_set = false; return MUDPT_OK; }  // likewise
-    if (!strcmp(name, "txt_split")) {  // the [W | W] copies are made while the weights are ingested: decide before the first mudpt_set_weight
-        if (m->any_weight_set) { set_error("model_set: txt_split must be set before the first mudpt_set_weight"); return MUDPT_ERR_STATE; }
-        m->txt.split = (value != 0 && m->dtype == MUDPT_F16) || m->exact;
-        return MUDPT_OK;
+    // Split operands (Tower::split).  Effective from the next forward: the low-half buffers and the e4m3 weights exist whenever
+    // the tower may split at all (vision tower: the parity mode MUDPT_F32; text tower: MUDPT_F16 and MUDPT_F32).
+    //   vis_lo / txt_lo          0 = no low halves, 1 = fp16 pairs (22 bits), 2 = e4m3 remainders on the fp8 matrix pipe (vision tower only)
+    //   txt_split                the round-2 name of txt_lo = 0 / 1
+    //   vis_sites / txt_sites    bit mask of the sites that take part (model.cpp Site: 1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj, 16 patch embed)
+    //   vis_exact_attn / txt_exact_attn   attention forward in fp32 (attention_exact.hip); parity mode only
+    for (Tower* t : {&m->vis, &m->txt}) {
+        const char* pre = t == &m->vis ? "vis_" : "txt_";
+        if (strncmp(name, pre, 4)) continue;
+        const char* k = name + 4;
+        if (!strcmp(k, "lo") || (t == &m->txt && !strcmp(k, "split"))) {
+            if (value != LO_NONE && !t->may_split) { set_error("model_set: %s needs a mode whose %s tower keeps low halves (dtype fp32%s)", name, t == &m->vis ? "vision" : "text", t == &m->txt ? " or fp16" : ""); return MUDPT_ERR_STATE; }
+            ARG_CHECK(value == LO_NONE || value == LO_F16 || (value == LO_F8 && !t->w.empty() && t->w[0].w_in8), "model_set: %s = %d is not available for this tower", name, value);
+            t->split = value;
+            m->text_valid = false;
+            return MUDPT_OK;
+        }
+        if (!strcmp(k, "sites")) { t->sites = value & 0x1f; m->text_valid = false; return MUDPT_OK; }
+        if (!strcmp(k, "exact_attn")) {
+            if (value && !(t->may_split && m->exact)) { set_error("model_set: %s needs the parity mode (dtype fp32)", name); return MUDPT_ERR_STATE; }
+            t->exact_attn = value != 0;
+            m->text_valid = false;
+            return MUDPT_OK;
+        }
     }
     set_error("model_set: unknown knob '%s'", name);
     return MUDPT_ERR_ARG;
@@ -1661,10 +1756,25 @@ extern "C" int mudpt_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int3
     a.aux = aux; a.ldaux = ldaux; a.patches = patches; a.seq_len = seq_len; a.pos = pos;
     return launch_gemm(dtype, epi, a, (hipStream_t)stream, o);
 }
-extern "C" int mudpt_gemm_gelu_split(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb, const float* bias,
-                                     void* u, int32_t ldu, void* g_hi, void* g_lo, int32_t ldg, void* stream) {
-    GemmArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias; a.out0 = u; a.ldo0 = ldu; a.out1 = g_hi; a.out1_lo = g_lo; a.ldo1 = ldg;
-    return launch_gemm(dtype, EPI_GELU, a, (hipStream_t)stream);
+extern "C" int mudpt_gemm_split(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const void* A, const void* A_lo, int32_t lo_mode, int32_t lda,
+                                const void* B, const void* B8, int32_t b8_scale, int32_t ldb, const float* bias, void* out0, int32_t ldo0, void* out1,
+                                void* out1_lo, int32_t out1_lo_mode, int32_t ldo1, const void* aux, int32_t ldaux, int32_t variant, void* stream) {
+    GemmOpts o;
+    o.variant = variant;
+    GemmArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias; a.out0 = out0; a.ldo0 = ldo0; a.out1 = out1; a.ldo1 = ldo1;
+    a.aux = aux; a.ldaux = ldaux; a.A_lo = A_lo; a.lo_mode = lo_mode; a.B8 = B8; a.b8_scale = b8_scale; a.out1_lo = out1_lo; a.out1_lo_mode = out1_lo ? out1_lo_mode : (int)LO_F16;
+    return launch_gemm(dtype, epi, a, (hipStream_t)stream, o);
+}
+extern "C" int mudpt_e4m3_from_f32(const float* in_host, uint8_t* out_host, size_t n, int32_t shift) {
+    ARG_CHECK(in_host && out_host, "e4m3_from_f32: null argument");
+    for (size_t i = 0; i < n; ++i) out_host[i] = f32_to_e4m3(std::ldexp(in_host[i], shift));
+    return MUDPT_OK;
+}
+extern "C" int mudpt_layernorm_fwd_split(int32_t dtype, const float* x, int32_t ldx, const float* gamma, const float* beta, void* out, void* out_lo, int32_t lo_mode,
+                                         int32_t ldo, int32_t rows, int32_t d, void* stream) {
+    LnFwdArgs a; a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.out = out; a.out_lo = out_lo; a.lo_mode = lo_mode; a.ldo = ldo; a.rows = rows; a.d = d;
+    ARG_CHECK(out_lo && (lo_mode == LO_F16 || lo_mode == LO_F8), "layernorm_fwd_split: needs out_lo and lo_mode 1 / 2");
+    return launch_ln_fwd(dtype, a, (hipStream_t)stream);
 }
 extern "C" int mudpt_layernorm_fwd(int32_t dtype, const float* x, int32_t ldx, const int32_t* row_index, const float* gamma, const float* beta, void* out,
                                    int32_t ldo, int32_t out_f32, float* mean, float* rstd, int32_t rows, int32_t d, void* stream) {
@@ -1735,9 +1845,10 @@ extern "C" int mudpt_attention_fwd(int32_t dtype, const void* qkv, void* out, fl
     a.tiled_fwd_16 = (causal & 2) != 0;  // 224 < L <= 640: the staged 16-query-block kernel instead of the resident form (A/B, tests)
     return launch_attn_fwd(dtype, a, (hipStream_t)stream);
 }
-extern "C" int mudpt_attention_fwd_exact(const float* qkv32, void* qkv_lp, void* out_hi, void* out_lo, int32_t ld_out, float* lse, int32_t B, int32_t L, int32_t H,
-                                         int32_t causal, void* stream) {
-    AttnArgs a; a.qkv32 = qkv32; a.qkv_lp = qkv_lp; a.out = out_hi; a.out_lo = out_lo; a.ld_out = ld_out; a.lse = lse; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;
+extern "C" int mudpt_attention_fwd_exact(const float* qkv32, void* qkv_lp, void* out_hi, void* out_lo, int32_t lo_mode, int32_t ld_out, float* lse, int32_t B, int32_t L,
+                                         int32_t H, int32_t causal, void* stream) {
+    ARG_CHECK(!out_lo || lo_mode == LO_F16 || lo_mode == LO_F8, "attention_fwd_exact: lo_mode must be 1 (fp16) or 2 (e4m3)");
+    AttnArgs a; a.qkv32 = qkv32; a.qkv_lp = qkv_lp; a.out = out_hi; a.out_lo = out_lo; a.lo_mode = out_lo ? lo_mode : (int)LO_F16; a.ld_out = ld_out; a.lse = lse; a.B = B; a.L = L; a.H = H; a.causal = causal != 0;
     return launch_attn_fwd_exact(a, (hipStream_t)stream);
 }
 extern "C" int mudpt_attention_bwd(int32_t dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int32_t B,

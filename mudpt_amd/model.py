@@ -152,8 +152,9 @@ class CustomCLIP(nn.Module):
         return "mudpt_prompt_learner.ctx" if self.variant == "mudpt" else "prompt_learner.ctx"
 
     def set_knob(self, name: str, value: int):
-        """``mudpt_model_set``: "gemm_variant", "lp_grad" any time; "txt_split" / "txt_trim" only through ``knobs=`` at construction
-        (before the weights / class prompts are ingested)."""
+        """``mudpt_model_set``: "gemm_variant", "lp_grad" and the split-operand knobs ("vis_lo", "txt_lo", "vis_sites", "txt_sites",
+        "vis_exact_attn", "txt_exact_attn": include/mudpt.h MUDPT_F32) any time; "txt_trim" / "txt_buckets" only through
+        ``knobs=`` at construction (before the class prompts are ingested)."""
         capi.check(self.lib.mudpt_model_set(self._h, name.encode(), int(value)), f"model_set({name})")
 
     def text_layout(self):

@@ -202,7 +202,9 @@ def test_two_processes_gloo_208_classes_match_reference(tmp_path, dtype):
     check_grads(z["grads"], og, dtype, "2 ranks, 208 classes")
     for rk in z["ranks"]:  # eval mode: same logits as the training forward (dropout-free model), cache reuse changes nothing
         assert torch.equal(rk["eval"], rk["eval_reuse"])
-        assert (rk["eval"] - rk["logits"]).abs().max().item() <= 1e-6
+        # a TRAINING forward of <= 8 images splits the contraction of out_proj / c_proj (a differently associated fp32 sum), an inference
+        # forward never does (its logits must not depend on the test batch's size): the two agree to that rounding (tests/helpers.py)
+        assert (rk["eval"] - rk["logits"]).abs().max().item() <= 6e-4
 
 
 def test_plugin_runs_class_parallel_at_world_2(tmp_path):

@@ -5,7 +5,7 @@ import torch
 
 from oracle import cocoop_oracle as CO
 from oracle import mudpt_oracle as O
-from tests.helpers import GoldenCase
+from tests.helpers import GoldenCase, assert_training_forward_is_the_inference_forward
 
 pytestmark = pytest.mark.gpu
 
@@ -66,7 +66,7 @@ def test_logits_loss_grads_match_reference(case, dtype):
     m.train()
     loss, logits2 = m.forward_backward(case.images, case.labels, return_logits=True)  # training mode: CE inside forward (:196-197)
     torch.cuda.synchronize()
-    assert torch.equal(logits2.cpu(), logits)  # same kernels, same order: bitwise
+    assert_training_forward_is_the_inference_forward(logits2, logits, dtype)  # same kernels; a tiny training batch may split K (tests/helpers.py)
     assert abs(loss.item() - case.loss) <= slack * LOGIT_ATOL[dtype]
     got = {k: v.detach().cpu() for k, v in m.grads().items()}
     taps = {}

@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from oracle import mudpt_oracle as O
-from tests.helpers import GoldenCase
+from tests.helpers import GoldenCase, assert_training_forward_is_the_inference_forward
 
 pytestmark = pytest.mark.gpu
 
@@ -79,7 +79,7 @@ def test_c208_logits_loss_grads_match_reference(case208, dtype):
             assert (got[k] - full).abs().max().item() <= GRAD_RTOL[dtype] * rms_g * 4 + 1e-9, k
         else:
             assert (got[k][::8, ::8] - sample).abs().max().item() <= GRAD_RTOL[dtype] * rms_g * 4 + 1e-9, k
-    assert torch.equal(m(case.images), logits)  # forward-only call: same kernels, same order
+    assert_training_forward_is_the_inference_forward(logits, m(case.images), dtype)  # forward-only call: same kernels; a 2-image training batch splits K
     m.close()
 
 
@@ -112,7 +112,7 @@ def test_c208_length_buckets_change_nothing(case208):
         torch.cuda.synchronize()
         out[nb] = (logits.cpu(), loss.item(), {k: g.detach().cpu().clone() for k, g in m.grads().items()})
         m.eval()
-        assert torch.equal(m(case.images).cpu(), out[nb][0])
+        assert_training_forward_is_the_inference_forward(out[nb][0], m(case.images), "fp16")
         m.close()
     print("text layouts (rows, buckets, longest):", rows)
     assert rows[1][1] == 1 and rows[1][0] == 208 * rows[1][2]

@@ -269,6 +269,23 @@ def test_training_trajectory_tracks_the_oracle(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_eval_logits_do_not_depend_on_the_test_batch_size(dtype):
+    """Inference forwards never split K: the logits of an image are bit-identical whether it arrives in a batch of 4, 2 or 1 --
+    a last, partial test batch gives the same numbers as a full one.  (A TRAINING forward of <= 8 ViT-B images may split out_proj / c_proj:
+    test_split_k_agrees_with_the_sequential_contraction.)"""
+    case = GoldenCase("mudpt_vitb16_b4")
+    m = build(case, dtype)
+    m.eval()
+    full = m(case.images).cpu()
+    for n in (2, 1):
+        assert torch.equal(m(case.images[:n]).cpu(), full[:n]), n
+    m.train()
+    _, train_logits = m.forward_backward(case.images, case.labels, return_logits=True)
+    assert not torch.equal(train_logits.cpu(), full)  # this shape's training forward does split (156 tiles): the knob is what differs
+    m.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 def test_split_k_agrees_with_the_sequential_contraction(dtype):
     """B = 4 ViT-B/16 (M = 804 rows): the vision tower's long-K store GEMMs (backward dfc K 3072, dqkv K 2304; forward c_proj K 3072 while the
     grid is at most 320 tiles of 64 x 64, i.e. up to 8 images) split K over up to four slices whose fp32 partials are summed in slice order

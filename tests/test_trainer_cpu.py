@@ -103,3 +103,26 @@ def test_device_prefetcher_is_transparent_without_a_gpu():
         for i, b in enumerate(got):
             assert b["impath"] == [str(i)] and torch.equal(b["img"].cpu(), batches[i]["img"]) and torch.equal(b["label"].cpu(), batches[i]["label"])
     assert list(DevicePrefetcher(Loader())) == []
+
+
+def test_prec_fp16_on_a_real_checkpoint_scale_is_called_out(capsys):
+    """PREC = "fp16" (the reference yamls' default) with exp(logit_scale) = 100, what every released CLIP checkpoint holds: the fp16 mode is
+    ~4e-3 from the reference's logits there, so the plugins say so once and name the setting that holds 1e-3 (VERDICT r3 item 7);
+    random-init weights (scale 14.29), the other PREC values and a missing logit_scale stay silent."""
+    import math
+    import torch
+    from mudpt_amd import trainer
+    trainer._warned_fp16_scale = False
+    real, init = {"logit_scale": torch.tensor(math.log(100.0))}, {"logit_scale": torch.tensor(math.log(1 / 0.07))}
+    assert not trainer.warn_if_fp16_misses_the_bound("fp16", init)
+    assert not trainer.warn_if_fp16_misses_the_bound("fp32", real)
+    assert not trainer.warn_if_fp16_misses_the_bound("amp", real)
+    assert not trainer.warn_if_fp16_misses_the_bound("fp16", None)
+    assert not trainer.warn_if_fp16_misses_the_bound("fp16", {})
+    assert capsys.readouterr().out == ""
+    assert trainer.warn_if_fp16_misses_the_bound("fp16", real)
+    out = capsys.readouterr().out
+    assert 'PREC "fp32"' in out and "4e-3" in out and "100.0" in out
+    assert trainer.warn_if_fp16_misses_the_bound("fp16", real)  # still reported to the caller ...
+    assert capsys.readouterr().out == ""                          # ... but printed once per process
+    assert trainer.precision_to_dtype("fp32") == "fp32" and trainer.precision_to_dtype("amp") == "bf16"

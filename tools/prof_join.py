@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--pmc-steps", type=int, required=True, help="bench steps (warm-up included) in each PMC run")
     ap.add_argument("--title", default="HBM-side bytes per kernel, joined with the kernel trace")
     ap.add_argument("--note", default="")
+    ap.add_argument("--stamp", default="", help="mudpt_amd.build.source_hash() of the library that was profiled")
     ap.add_argument("--out-md", required=True)
     ap.add_argument("--out-json", required=True)
     a = ap.parse_args()
@@ -119,6 +120,7 @@ def main():
         f.write("\n| hardware queue | launches / step | kernel ms / step | idle between kernels ms / step | mean gap us |\n|---|---:|---:|---:|---:|\n")
         for qd in out["queues"]:
             f.write(f"| {qd['queue']} | {qd['launches_per_step']:.1f} | {qd['busy_ms_per_step']:.2f} | {qd['gap_ms_per_step']:.2f} | {qd['mean_gap_us']:.1f} |\n")
+    out["source_hash"] = a.stamp
     json.dump(out, open(a.out_json, "w"), indent=1)
     print(json.dumps(out["classes"], indent=1))
 

@@ -13,7 +13,8 @@ rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- pyt
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- python3 "$ROOT/bench.py" --steps $PS --warmup $PW --no-cpu-baseline --no-parity-mode --no-profile "$@" > "$OUT/fetch.log" 2>&1 || { tail -5 "$OUT/fetch.log"; exit 1; }
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o w --output-format csv -- python3 "$ROOT/bench.py" --steps $PS --warmup $PW --no-cpu-baseline --no-parity-mode --no-profile "$@" > "$OUT/write.log" 2>&1 || { tail -5 "$OUT/write.log"; exit 1; }
 T=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1); F=$(find "$OUT/fetch" -name "*counter_collection.csv" | head -1); W=$(find "$OUT/write" -name "*counter_collection.csv" | head -1)
-python3 "$ROOT/tools/prof_join.py" --trace "$T" --fetch "$F" --write "$W" --steps $((TS + TW + HB)) --pmc-steps $((PS + PW)) \
+STAMP=$(cd "$ROOT" && python3 -c "from mudpt_amd import build; print(build.source_hash())")
+python3 "$ROOT/tools/prof_join.py" --trace "$T" --fetch "$F" --write "$W" --steps $((TS + TW + HB)) --pmc-steps $((PS + PW)) --stamp "$STAMP" \
     --title "HBM-side bytes per kernel joined with the kernel trace ($TAG)" \
     --note "Command: \`python3 bench.py --steps $TS --warmup $TW --no-cpu-baseline --no-parity-mode $*\` under \`rocprofv3 --kernel-trace --stats\` ($((TS + TW + HB)) steps in the trace: warm-up, timed, and the $HB steps of the HBM-kernel pass); PMC passes: the same with \`--steps $PS --warmup $PW --no-profile\` under \`--pmc FETCH_SIZE\` / \`--pmc WRITE_SIZE\`." \
     --out-md "$OUT/bytes_per_step.md" --out-json "$OUT/bytes_per_step.json" > "$OUT/join.log" 2>&1 || { tail -5 "$OUT/join.log"; exit 1; }
