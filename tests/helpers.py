@@ -61,7 +61,7 @@ class GoldenCase:
 # c_proj over K slices (a differently associated fp32 sum flips the T rounding of ~1 % of their outputs); an INFERENCE forward never does, so
 # that the logits of an image do not depend on the size of the test batch it arrives in.  At such batches the two forwards
 # agree to that rounding only (measured 2.8e-4 fp16 / 5e-3 bf16 at logit scale 14.29); above them, and in the parity mode, bit for bit.
-FWD_SPLIT_TOL = {"fp16": 6e-4, "bf16": 8e-3, "fp32": 0.0}
+FWD_SPLIT_TOL = {"fp16": 6e-4, "bf16": 1.2e-2, "fp32": 0.0}  # (CoCoOp, where the image features enter twice: 9.3e-3 bf16)
 
 
 def assert_training_forward_is_the_inference_forward(train_logits, eval_logits, dtype):

@@ -123,11 +123,13 @@ def test_logits_at_scale_100_within_1e_3(name):
         m.close()
 
 
-# name -> knobs of one row of DESIGN.md 2's ablation table (site masks: 1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj, 16 patch embed)
+# name -> knobs of one row of DESIGN.md 2's ablation table (the same rows are timed at B 256 by tools/parity_ablation_bench.py) (site masks: 1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj, 16 patch embed)
 ABLATION = [
     ("fp16 mode (vision fp16; text: pairs, fp16 attention)", None, 2e-2),
     ("text exact; vision fp16 everywhere", {"vis_lo": 0}, 6e-3),
     ("text exact; vision e4m3 lo at c_fc, c_proj", {"vis_sites": 4 + 8}, 2.5e-3),
+    ("text exact; vision e4m3 lo at c_fc, c_proj, patch", {"vis_sites": 4 + 8 + 16}, 2.5e-3),
+    ("text exact; vision e4m3 lo at out_proj, c_fc, c_proj, patch", {"vis_sites": 2 + 4 + 8 + 16}, 2e-3),
     ("text exact; vision e4m3 lo at all four GEMMs", {"vis_sites": 15}, 2e-3),
     ("parity mode: + split pixels", {}, 1e-3),
     ("parity mode with fp16 pairs in the vision tower", {"vis_lo": 1}, 1e-3),
