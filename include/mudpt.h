@@ -218,7 +218,9 @@ int mudpt_profile_read_classes(mudpt_model* m, double* ms, double* work, int64_t
 int mudpt_gemm(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda,
                const void* B, int32_t ldb, const float* bias, void* out0, int32_t ldo0, void* out1, int32_t ldo1,
                const void* aux, int32_t ldaux, int32_t patches, int32_t seq_len, const float* pos, int32_t variant, void* stream);
-/* variant: kernel-choice knob for tests / tuning (0 = the default dispatch). */
+/* variant: kernel-choice knob for tests / tuning (0 = the default dispatch).  Bit 16: allow split K.  Bit 17: QuickGELU' in 8 bits (what the
+ * bf16 mode keeps for the backward instead of u): epilogue 1 writes out0 = byte codes rint((QuickGELU'(u) + 0.1) * 212) with a row stride of
+ * ldo0 BYTES, epilogue 3 reads such codes from aux (row stride ldaux bytes). */
 /* A GEMM with a SPLIT A operand (the forward GEMMs of the parity mode): A = T(v), A_lo = the remainder v - A in a second buffer
  * with the row stride of A in bytes.  lo_mode 1: A_lo holds T values and a second pass contracts it against the same B (22 bits); lo_mode 2:
  * A_lo holds OCP e4m3 bytes of (v - A) * 2^12 (the first K bytes of each row) and the second pass runs on the MX-scaled fp8 matrix

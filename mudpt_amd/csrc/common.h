@@ -57,6 +57,23 @@ __device__ inline float quick_gelu_grad(float u) {
     return s * (1.0f + 1.702f * u * (1.0f - s));
 }
 
+// QuickGELU'(u) in 8 bits (GemmArgs::gelu_q8; the bf16 throughput mode): the backward needs u only through QuickGELU'(u), which lives in
+// [-0.0998, 1.0998].  c_fc's epilogue stores code = rint((g' + GQ8_OFF) * GQ8_SCALE) in [0, 254] instead of u in T (1 byte instead of 2 per
+// MLP activation, written once and read once per step), and the d(QuickGELU) epilogue multiplies by the decoded value: absolute error
+// <= 0.5 / GQ8_SCALE = 2.4e-3, the size of bf16's own rounding of a value near 1 (2^-9 = 2.0e-3).
+constexpr float GQ8_SCALE = 212.f, GQ8_OFF = 0.1f;
+__device__ inline uint32_t gelu_grad_q8x4(float u0, float u1, float u2, float u3) {  // byte j = code of u_j
+    uint32_t w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32((quick_gelu_grad(u0) + GQ8_OFF) * GQ8_SCALE, 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32((quick_gelu_grad(u1) + GQ8_OFF) * GQ8_SCALE, 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32((quick_gelu_grad(u2) + GQ8_OFF) * GQ8_SCALE, 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32((quick_gelu_grad(u3) + GQ8_OFF) * GQ8_SCALE, 3, w);
+    return w;
+}
+__device__ inline float gelu_grad_from_q8(uint32_t word, int j) {  // decoded QuickGELU' of byte j
+    return __builtin_fmaf((float)((word >> (8 * j)) & 0xffu), 1.f / GQ8_SCALE, -GQ8_OFF);
+}
+
 // Split operands (Tower::split_mode).  A forward GEMM's A operand v is stored as hi = T(v) in the ordinary operand buffer plus the
 // remainder lo = v - hi in a SECOND buffer with the same row stride in BYTES, in one of two forms:
 //   LO_F16: lo as T.  hi + lo carries 22 bits; the GEMM runs a second pass over lo against the same weights (what the text tower uses: it

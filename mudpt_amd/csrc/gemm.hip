@@ -186,8 +186,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
                 typename T::vec4 o = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
                 *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = o;
             } else if constexpr (EPI == EPI_GELU) {
-                typename T::vec4 u = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
-                *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = u;
+                if (p.gelu_q8) {  // the backward's QuickGELU'(u) in 8 bits instead of u (common.h)
+                    *(uint32_t*)((char*)p.out0 + orow * p.ldo0 + n) = gelu_grad_q8x4(v[0], v[1], v[2], v[3]);
+                } else {
+                    typename T::vec4 u = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
+                    *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = u;
+                }
                 if (p.out1_lo) {  // split operand (common.h LoMode): the next GEMM's second pass contracts over the low half
                     typename T::vec4 g, lo;
                     float rem[4];
@@ -204,9 +208,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
                 const f32x4 r4 = *(const f32x4*)((const float*)p.aux + orow * p.ldaux + n);
                 *(f32x4*)((float*)p.out0 + orow * p.ldo0 + n) = v + r4;
             } else if constexpr (EPI == EPI_GELU_BWD) {
-                const typename T::vec4 u = *(const typename T::vec4*)((const elem*)p.aux + orow * p.ldaux + n);
-                typename T::vec4 o = {(elem)(v[0] * quick_gelu_grad((float)u[0])), (elem)(v[1] * quick_gelu_grad((float)u[1])),
-                                      (elem)(v[2] * quick_gelu_grad((float)u[2])), (elem)(v[3] * quick_gelu_grad((float)u[3]))};
+                typename T::vec4 o;
+                if (p.gelu_q8) {
+                    const uint32_t w = *(const uint32_t*)((const char*)p.aux + orow * p.ldaux + n);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = (elem)(v[c] * gelu_grad_from_q8(w, c));
+                } else {
+                    const typename T::vec4 u = *(const typename T::vec4*)((const elem*)p.aux + orow * p.ldaux + n);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = (elem)(v[c] * quick_gelu_grad((float)u[c]));
+                }
                 *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = o;
             } else if constexpr (EPI == EPI_PATCH) {
                 const f32x4 q4 = *(const f32x4*)(posrow + n);
@@ -339,6 +350,7 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const Gemm
     ARG_CHECK(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && ((uintptr_t)a.out0 % 16 == 0), "gemm: operands must be 16-byte aligned");
     if (epi == EPI_GELU) ARG_CHECK(a.out1 && a.ldo1 >= a.N && a.ldo1 % 4 == 0, "gemm: gelu epilogue needs out1");
     ARG_CHECK(!a.out1_lo || a.out1_lo_mode == LO_F16 || a.out1_lo_mode == LO_F8, "gemm: bad out1_lo_mode %d", a.out1_lo_mode);
+    ARG_CHECK(!a.gelu_q8 || ((epi == EPI_GELU && !a.out1_lo) || epi == EPI_GELU_BWD), "gemm: gelu_q8 belongs to the QuickGELU epilogues (1 without a split output, 3)");
     ARG_CHECK(a.lo_mode == LO_NONE || a.lo_mode == LO_F16 || a.lo_mode == LO_F8, "gemm: bad lo_mode %d", a.lo_mode);
     if (a.lo_mode != LO_NONE) ARG_CHECK(a.A_lo && (uintptr_t)a.A_lo % 16 == 0, "gemm: a split operand needs its low half (16-byte aligned)");
     if (a.lo_mode == LO_F8) {

@@ -45,6 +45,8 @@ __device__ inline void vmcnt() {
 // writes 632 -> 900 MB (partial lines are no longer combined in the L2) and the step 25.10 -> 25.38 ms.  Plain policy everywhere; the parameters stay for the next experiment.
 constexpr int EPI_GELU_SPLIT = 100;   // EPI_GELU with out1 as a split operand: out1 = hi(gelu(u)), out1_lo = the remainder as T (common.h LO_F16)
 constexpr int EPI_GELU_SPLIT8 = 101;  // ... the remainder as e4m3 bytes (LO_F8)
+constexpr int EPI_GELU_Q8 = 102;      // EPI_GELU with out0 = 8-bit codes of QuickGELU'(u) instead of u (GemmArgs::gelu_q8, common.h)
+constexpr int EPI_GELU_BWD_Q8 = 103;  // EPI_GELU_BWD reading such codes from aux
 
 // Split A operand (common.h LoMode; GemmArgs::A_lo): a tile's K loop is two passes -- K / 64 steps of A against B, then the low half:
 // LO_F16: K / 64 more steps of A_lo against the same B (fp16 MFMA; the text tower, which needs all 22 bits);
@@ -82,18 +84,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     const auto rsB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(F8 ? p.B8 : p.B), 0, (int)((size_t)p.N * p.ldb * 2 < 0xffffffffull ? (size_t)p.N * p.ldb * 2 : 0xffffffffull), 0x00020000);
 
     // epilogue operands through bounds-checked descriptors as well (out-of-range lanes get offset OOB: dropped / read 0)
-    static_assert(EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_SPLIT8 || EPI == EPI_GELU_BWD || EPI == EPI_STORE_F32, "epilogue not built for gemm_pp");
-    constexpr bool GELU = (EPI == EPI_GELU || EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_SPLIT8);
+    static_assert(EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_SPLIT8 || EPI == EPI_GELU_BWD || EPI == EPI_STORE_F32 ||
+                  EPI == EPI_GELU_Q8 || EPI == EPI_GELU_BWD_Q8, "epilogue not built for gemm_pp");
+    constexpr bool GELU = (EPI == EPI_GELU || EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_SPLIT8 || EPI == EPI_GELU_Q8);
     constexpr int OOB = (int)0x80000000;
     constexpr bool OUT_F32 = (EPI == EPI_STORE_F32);
     // B fragment rows: permuted (a lane ends up with 16 consecutive columns = 32 bytes of T) for the T outputs, natural
     // (4 consecutive columns per sub-tile = 16 bytes of fp32) for the fp32 output; see the epilogue.
     constexpr bool NAT = OUT_F32;
-    constexpr int NST = (EPI == EPI_STORE || EPI == EPI_GELU_BWD) ? 16 : (EPI == EPI_GELU_SPLIT ? 48 : (EPI == EPI_GELU_SPLIT8 ? 40 : 32));  // stores per wave per tile, exact
-    const auto rsOut0 = __builtin_amdgcn_make_buffer_rsrc(p.out0, 0, p.M * p.ldo0 * (OUT_F32 ? 4 : 2), 0x00020000);
+    constexpr int NST = (EPI == EPI_STORE || EPI == EPI_GELU_BWD || EPI == EPI_GELU_BWD_Q8) ? 16 : (EPI == EPI_GELU_SPLIT ? 48 : (EPI == EPI_GELU_SPLIT8 ? 40 : (EPI == EPI_GELU_Q8 ? 24 : 32)));  // stores per wave per tile, exact
+    const auto rsOut0 = __builtin_amdgcn_make_buffer_rsrc(p.out0, 0, p.M * p.ldo0 * (OUT_F32 ? 4 : (EPI == EPI_GELU_Q8 ? 1 : 2)), 0x00020000);
     const auto rsOut1 = __builtin_amdgcn_make_buffer_rsrc(p.out1, 0, GELU ? p.M * p.ldo1 * 2 : 0, 0x00020000);
     const auto rsOut1Lo = __builtin_amdgcn_make_buffer_rsrc(p.out1_lo, 0, (EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_SPLIT8) ? p.M * p.ldo1 * 2 : 0, 0x00020000);
-    const auto rsAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0, EPI == EPI_GELU_BWD ? p.M * p.ldaux * 2 : 0, 0x00020000);
+    const auto rsAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0, EPI == EPI_GELU_BWD ? p.M * p.ldaux * 2 : (EPI == EPI_GELU_BWD_Q8 ? p.M * p.ldaux : 0), 0x00020000);
     const auto rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
     bool epi_pending = false;  // the previous step ended with an epilogue: NST stores sit in the VMEM queue
 
@@ -293,6 +296,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
 #pragma unroll
                         for (int c = 0; c < 4; ++c) acc[i][j][c] *= quick_gelu_grad((float)u[i][j >> 1][4 * (j & 1) + c]);
             }
+            if constexpr (EPI == EPI_GELU_BWD_Q8) {
+                u32x4 q[8];  // 16 byte codes: this lane's 16 columns of row i
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, i < ni ? row_off(i, p.ldaux, 1, n) : OOB, 0, LD);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[i][j][c] *= gelu_grad_from_q8(q[i][j], c);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- pass 2: stores only (exactly NST per wave).  One CU drains ~16 bytes per clock (tools/probes/store_pattern.hip:
             // 31-33 GB/s per CU whatever the lane -> address map), so a 128 KiB tile costs ~4 us that nothing overlaps.
@@ -306,12 +320,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                     for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsOut0, row_off(i, p.ldo0, 4, n + 16 * j), 0, ST);
                 } else {
                     vec8 o0, o1;
+                    if constexpr (EPI == EPI_GELU_Q8) {  // 16 byte codes of QuickGELU'(u): one 16-byte store instead of u's two
+                        u32x4 q;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { o0[c] = (elem)acc[i][0][c]; o0[4 + c] = (elem)acc[i][1][c]; o1[c] = (elem)acc[i][2][c]; o1[4 + c] = (elem)acc[i][3][c]; }
-                    const int off = row_off(i, p.ldo0, 2, n);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut0, off, 0, ST);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut0, off, 16, ST);
-                    if constexpr (EPI == EPI_GELU) {
+                        for (int j = 0; j < 4; ++j) q[j] = gelu_grad_q8x4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(q, rsOut0, row_off(i, p.ldo0, 1, n), 0, ST);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { o0[c] = (elem)acc[i][0][c]; o0[4 + c] = (elem)acc[i][1][c]; o1[c] = (elem)acc[i][2][c]; o1[4 + c] = (elem)acc[i][3][c]; }
+                        const int off = row_off(i, p.ldo0, 2, n);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut0, off, 0, ST);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut0, off, 16, ST);
+                    }
+                    if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_Q8) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             o0[c] = (elem)quick_gelu(acc[i][0][c]); o0[4 + c] = (elem)quick_gelu(acc[i][1][c]);
@@ -517,9 +538,9 @@ static int launch_pp_t(int epi, const GemmArgs& a, hipStream_t s, const GemmOpts
     switch (epi) {
         case EPI_STORE: return launch_pp<T, EPI_STORE>(a, s, o);
         case EPI_GELU:
-            if (!a.out1_lo) return launch_pp<T, EPI_GELU>(a, s, o);
+            if (!a.out1_lo) return a.gelu_q8 ? launch_pp<T, EPI_GELU_Q8>(a, s, o) : launch_pp<T, EPI_GELU>(a, s, o);
             return a.out1_lo_mode == LO_F8 ? launch_pp<T, EPI_GELU_SPLIT8>(a, s, o) : launch_pp<T, EPI_GELU_SPLIT>(a, s, o);
-        case EPI_GELU_BWD: return launch_pp<T, EPI_GELU_BWD>(a, s, o);
+        case EPI_GELU_BWD: return a.gelu_q8 ? launch_pp<T, EPI_GELU_BWD_Q8>(a, s, o) : launch_pp<T, EPI_GELU_BWD>(a, s, o);
         case EPI_STORE_F32: return launch_pp<T, EPI_STORE_F32>(a, s, o);
     }
     set_error("gemm_pp: epilogue %d is not built for the ping-pong kernel", epi);
@@ -532,6 +553,7 @@ int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s, const G
     ARG_CHECK(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldo0 % 8 == 0, "gemm_pp: strides must be multiples of 8");
     ARG_CHECK(!a.out1_lo || (uintptr_t)a.out1_lo % 16 == 0, "gemm_pp: out1_lo must be 16-byte aligned");
     // epilogue offsets are 32-bit and rely on the descriptors' range check for rows >= M
+    ARG_CHECK(!a.gelu_q8 || (a.lo_mode == LO_NONE && a.ldo0 % 16 == 0 && a.ldaux % 16 == 0), "gemm_pp: gelu_q8 needs 16-byte row strides and no split operand");
     ARG_CHECK((size_t)a.M * a.ldo0 * (epi == EPI_STORE_F32 ? 4 : 2) < 0x7fffffffull && (size_t)a.M * (size_t)(a.ldo1 > a.ldaux ? a.ldo1 : a.ldaux) * 2 < 0x7fffffffull, "gemm_pp: output larger than 2 GiB");
     if (dtype == DT_BF16) return launch_pp_t<BF16>(epi, a, s, o);
     if (dtype == DT_F16) return launch_pp_t<F16>(epi, a, s, o);

@@ -33,6 +33,9 @@ struct GemmArgs {
     const void* A_lo = nullptr; int lo_mode = LO_NONE;
     const void* B8 = nullptr; int b8_scale = 127;
     const void* aux = nullptr; int ldaux = 0;
+    // QuickGELU' in 8 bits (common.h): EPI_GELU stores out0 = byte codes of QuickGELU'(u) (row stride ldo0 BYTES) instead of u in T;
+    // EPI_GELU_BWD reads such codes from aux (row stride ldaux BYTES) instead of u
+    bool gelu_q8 = false;
     int flags = 0;                 // bit 0: no XCD remap of the block id (tuning)
     int patches = 0, seq_len = 0;  // EPI_PATCH: P, L
     const float* pos = nullptr;    // EPI_PATCH: [1 + P, N]

@@ -214,6 +214,9 @@ struct mudpt_model {
     // RMS; CoCoOp's meta_net gradients reach the edge of the test's error model), step 26.5 -> 25.6 ms.  Not the default: the parity
     // mode exists for accuracy.
     bool lp_grad = false;
+    // bf16 mode: c_fc stores QuickGELU'(u) in 8 bits for the backward instead of u in T (common.h gelu_grad_q8x4): -158 MB written and
+    // -158 MB read per MLP and step at an error of 2.4e-3 on a factor in [-0.1, 1.1] -- bf16's own grade.  Knob gelu_q8.
+    bool gelu_q8 = false;
     bool lp_upd = false;   // the forward's update stream (out_proj / c_proj results added by the next LayerNorm) in T instead of fp32: bf16 mode
     // per-handle tuning knobs (mudpt_model_set): nothing here is process-global, two models in one process do not interfere
     int gemm_variant = 0;
@@ -489,6 +492,7 @@ extern "C" int mudpt_create(const mudpt_config* c, mudpt_model** out) {
     // with fp16 activation gradients, as the reference's own fp16 model has them: gradient errors +30 %, -0.9 ms per step; knob lp_grad = 0)
     m->lp_grad = (c->dtype == MUDPT_BF16 || c->dtype == MUDPT_F32);
     m->lp_upd = (c->dtype == MUDPT_BF16);
+    m->gelu_q8 = (c->dtype == MUDPT_BF16);
     m->cocoop = cocoop;
     m->ct = c->n_cls;
     if (cocoop) m->cfg.depth = 1;  // no deep prompts
@@ -924,6 +928,7 @@ static int block_fwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s, boo
     GemmArgs f; f.A = t.h_sel; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = S; f.N = 4 * d; f.K = d; f.bias = w.b_fc;
     split_operand(f, m_fc, t.h_sel_lo, w.w_fc8, w.s_fc8);
     f.out0 = t.u_sel; f.ldo0 = 4 * d; f.out1 = t.g_sel; f.ldo1 = 4 * d;
+    f.gelu_q8 = m->gelu_q8 && t.split == LO_NONE;
     if (m_proj != LO_NONE) { f.out1_lo = t.g_sel_lo; f.out1_lo_mode = m_proj; }
     TRY(gemm_call(m, EPI_GELU, f, s));
     GemmArgs p; p.A = t.g_sel; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = S; p.N = d; p.K = 4 * d; p.bias = w.b_proj;
@@ -1019,6 +1024,7 @@ static int block_fwd(mudpt_model* m, Tower& t, int i, int nseq, const float* spl
     GemmArgs f; f.A = t.h; f.lda = d; f.B = w.w_fc; f.ldb = d; f.M = M; f.N = 4 * d; f.K = d; f.bias = w.b_fc; f.out0 = a.u; f.ldo0 = 4 * d;
     split_operand(f, m_fc, t.h_lo, w.w_fc8, w.s_fc8);
     f.out1 = t.g; f.ldo1 = 4 * d;
+    f.gelu_q8 = m->gelu_q8 && t.split == LO_NONE;  // a.u then holds byte codes of QuickGELU'(u) (rows of 4 d bytes)
     if (m_proj != LO_NONE) { f.out1_lo = t.g_lo; f.out1_lo_mode = m_proj; }
     TRY(gemm_call(m, EPI_GELU, f, s));
     GemmArgs p; p.A = t.g; p.lda = 4 * d; p.B = w.w_proj; p.ldb = 4 * d; p.M = M; p.N = d; p.K = 4 * d; p.bias = w.b_proj; p.out0 = t.upd; p.ldo0 = d;
@@ -1036,6 +1042,7 @@ static int block_bwd_tail(mudpt_model* m, Tower& t, int nseq, hipStream_t s) {
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
     GemmArgs g1; g1.A = t.dsel_lp; g1.lda = d; g1.B = w.w_proj_t; g1.ldb = d; g1.M = S; g1.N = 4 * d; g1.K = d; g1.out0 = t.g_sel; g1.ldo0 = 4 * d; g1.aux = t.u_sel; g1.ldaux = 4 * d;
+    g1.gelu_q8 = m->gelu_q8 && t.split == LO_NONE;  // as the forward stored it (block_fwd_tail)
     TRY(gemm_call(m, EPI_GELU_BWD, g1, s, !t.causal));
     GemmArgs g2; g2.A = t.g_sel; g2.lda = 4 * d; g2.B = w.w_fc_t; g2.ldb = 4 * d; g2.M = S; g2.N = d; g2.K = 4 * d; g2.out0 = t.h_sel; g2.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g2, s, !t.causal));
@@ -1098,6 +1105,7 @@ static int block_bwd(mudpt_model* m, Tower& t, int i, int nseq, hipStream_t s, f
     BlockW& w = t.w[i];
     BlockAct& a = t.a[i];
     GemmArgs g1; g1.A = t.dx_lp; g1.lda = d; g1.B = w.w_proj_t; g1.ldb = d; g1.M = M; g1.N = 4 * d; g1.K = d; g1.out0 = t.g; g1.ldo0 = 4 * d; g1.aux = a.u; g1.ldaux = 4 * d;
+    g1.gelu_q8 = m->gelu_q8 && t.split == LO_NONE;  // as the forward stored it (block_fwd)
     TRY(gemm_call(m, EPI_GELU_BWD, g1, s, !t.causal));
     GemmArgs g2; g2.A = t.g; g2.lda = 4 * d; g2.B = w.w_fc_t; g2.ldb = 4 * d; g2.M = M; g2.N = d; g2.K = 4 * d; g2.out0 = t.h; g2.ldo0 = d;
     TRY(gemm_call(m, EPI_STORE, g2, s, !t.causal));
@@ -1631,6 +1639,7 @@ extern "C" int mudpt_model_set(mudpt_model* m, const char* name, int32_t value) 
     // both stream copies are always allocated.  lp_grad = 0 (bf16 mode) also returns the forward's update stream to fp32, as before the two were separate knobs
     if (!strcmp(name, "lp_grad")) { m->lp_grad = value != 0; if (m->dtype == MUDPT_BF16) m->lp_upd = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "lp_upd")) { m->lp_upd = value != 0; return MUDPT_OK; }
+    if (!strcmp(name, "gelu_q8")) { m->gelu_q8 = value != 0; return MUDPT_OK; }  // between steps only: the backward decodes what the forward stored
     if (!strcmp(name, "txt_trim")) { m->txt_trim = value != 0; m->prompts_set = false; return MUDPT_OK; }  // read by the next mudpt_set_class_prompts
     if (!strcmp(name, "attn_two_kernels")) { m->attn_two_kernels = value != 0; return MUDPT_OK; }
     if (!strcmp(name, "fwd_split_k")) { m->fwd_split_k = value != 0; return MUDPT_OK; }
@@ -1744,7 +1753,7 @@ extern "C" int mudpt_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int3
                           const float* bias, void* out0, int32_t ldo0, void* out1, int32_t ldo1, const void* aux, int32_t ldaux, int32_t patches,
                           int32_t seq_len, const float* pos, int32_t variant, void* stream) {
     GemmOpts o;
-    o.variant = variant & ~0x10000;
+    o.variant = variant & ~0x30000;
     if (variant & 0x10000) {  // unit-test hook: allow split K, with a per-device scratch made on first use (never freed)
         static float* scratch[64] = {};
         const int dev = current_device();
@@ -1754,6 +1763,7 @@ extern "C" int mudpt_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int3
     }
     GemmArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias; a.out0 = out0; a.ldo0 = ldo0; a.out1 = out1; a.ldo1 = ldo1;
     a.aux = aux; a.ldaux = ldaux; a.patches = patches; a.seq_len = seq_len; a.pos = pos;
+    a.gelu_q8 = (variant & 0x20000) != 0;  // unit-test hook: QuickGELU' in 8 bits (epilogues 1 / 3; ldo0 / ldaux are then BYTE strides)
     return launch_gemm(dtype, epi, a, (hipStream_t)stream, o);
 }
 extern "C" int mudpt_gemm_split(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const void* A, const void* A_lo, int32_t lo_mode, int32_t lda,

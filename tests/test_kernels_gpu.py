@@ -110,6 +110,22 @@ def test_gemm_epilogues(lib, dtype, shape):
     ud = upre.double()
     s = torch.sigmoid(1.702 * ud)
     torch.testing.assert_close(out.cpu().double(), acc * (s * (1 + 1.702 * ud * (1 - s))), **tol)
+    # 1 / 3 with QuickGELU' in 8 bits (variant bit 17; what the bf16 mode keeps for the backward instead of u): the forward writes byte codes
+    # rint((g' + 0.1) * 212), the backward multiplies by the decoded value -- absolute error <= 0.5 / 212 on a factor in [-0.1, 1.1]
+    Q8 = 0x20000
+    codes = torch.zeros(M, N, device="cuda", dtype=torch.uint8)
+    gl2 = torch.empty(M, N, device="cuda", dtype=tt)
+    gemm(lib, dt, 1, Ad, Bd, bias=bd, out0=codes, out1=gl2, variant=Q8)
+    assert torch.equal(gl2, gl)
+    sr = torch.sigmoid(1.702 * uref)
+    gp = sr * (1 + 1.702 * uref * (1 - sr))
+    want = torch.round((gp + 0.1) * 212.0)
+    assert (codes.cpu().double() - want).abs().max().item() <= 1 and ((codes.cpu().double() - want).abs() > 0).double().mean().item() < 0.02  # ties / 1-ulp exp
+    assert ((codes.cpu().double() / 212.0 - 0.1) - gp).abs().max().item() <= 0.5 / 212 + 1e-3
+    out8 = torch.empty(M, N, device="cuda", dtype=tt)
+    cq = torch.randint(0, 255, (M, N), generator=g, dtype=torch.uint8)
+    gemm(lib, dt, 3, Ad, Bd, out0=out8, aux=cq.cuda(), variant=Q8)
+    torch.testing.assert_close(out8.cpu().double(), acc * (cq.double() / 212.0 - 0.1), **tol)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
