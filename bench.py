@@ -71,8 +71,8 @@ def cpu_baseline(n_cls: int = 11, iters: int = 12):
 PEAK_HBM_GBS = 8000.0  # HBM3E spec (MI355X_MICROARCH.md; ~6300 GB/s achievable by a streaming copy)
 # tools/prof_join.py output of the same command under rocprofv3 (separate --pmc FETCH_SIZE / WRITE_SIZE passes; tools/profile_round.sh),
 # committed per workload: (arch, batch, classes, dtype) -> profiles/<tag>_bytes_per_step.json
-TRAFFIC_TAGS = {("vit_b16", 256, 11, "bf16"): "r03", ("vit_b16", 256, 11, "fp16"): "r03_fp16", ("vit_b16", 256, 11, "fp32"): "r03_fp32",
-                ("vit_b16", 256, 1000, "bf16"): "r03_c1000", ("vit_l14_336", 128, 1000, "bf16"): "r03_vitl"}
+TRAFFIC_TAGS = {("vit_b16", 256, 11, "bf16"): "r04", ("vit_b16", 256, 11, "fp16"): "r04_fp16", ("vit_b16", 256, 11, "fp32"): "r04_fp32",
+                ("vit_b16", 256, 1000, "bf16"): "r04_c1000", ("vit_l14_336", 128, 1000, "bf16"): "r04_vitl"}
 
 
 def traffic_json(arch, B, C, dtype):
