@@ -88,6 +88,17 @@ enum LoMode : int { LO_NONE = 0, LO_F16 = 1, LO_F8 = 2 };
 constexpr int LO8_SHIFT = 12;
 constexpr int LO8_SCALE_E8M0 = 127 - LO8_SHIFT;  // the MX block scale 2^-LO8_SHIFT of the fp8 pass's activation operand
 
+// T(v) of a value an epilogue has just computed, through an opaque register: the conversion then rounds the fp32 VALUE.  With -ffp-contract=fast
+// (hipcc's default) the compiler may fold the multiply / add that produced v into the conversion (v_fma_mixlo_f16: ONE rounding of the exact
+// result) in one kernel and not in another, and the same operands then come out one ulp of T apart depending on which kernel ran the shape --
+// round 4: the QuickGELU epilogues of gemm_nt and gemm_pp, which made a trimmed text tower (small-tile kernel) differ from the untrimmed one
+// (persistent kernel) by 2e-3 of a gradient's rms where they used to agree to 1e-6.
+template <typename E>
+__device__ inline E round_to(float v) {
+    asm volatile("" : "+v"(v));
+    return (E)v;
+}
+
 // hi = T(v); returns the fp32 remainder v - hi.  The value passes through an opaque register first: with -ffp-contract=fast (hipcc's
 // default) the compiler may form `hi` from the UNROUNDED product that made v (v_fma_mixlo_f16: one rounding) in one place and from the
 // rounded v in another; on exact ties the two disagree and hi + lo is then off by a whole ulp of T (measured in round 3: 1 element in

@@ -183,13 +183,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
                 v += b4;
             }
             if constexpr (EPI == EPI_STORE) {
-                typename T::vec4 o = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
+                typename T::vec4 o = {round_to<elem>(v[0]), round_to<elem>(v[1]), round_to<elem>(v[2]), round_to<elem>(v[3])};
                 *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = o;
             } else if constexpr (EPI == EPI_GELU) {
                 if (p.gelu_q8) {  // the backward's QuickGELU'(u) in 8 bits instead of u (common.h)
                     *(uint32_t*)((char*)p.out0 + orow * p.ldo0 + n) = gelu_grad_q8x4(v[0], v[1], v[2], v[3]);
                 } else {
-                    typename T::vec4 u = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
+                    typename T::vec4 u = {round_to<elem>(v[0]), round_to<elem>(v[1]), round_to<elem>(v[2]), round_to<elem>(v[3])};
                     *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = u;
                 }
                 if (p.out1_lo) {  // split operand (common.h LoMode): the next GEMM's second pass contracts over the low half
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
                     if (p.out1_lo_mode == LO_F8) *(uint32_t*)((char*)p.out1_lo + orow * p.ldo1 * 2 + n) = pack_lo8(rem[0], rem[1], rem[2], rem[3]);
                     else *(typename T::vec4*)((elem*)p.out1_lo + orow * p.ldo1 + n) = lo;
                 } else {
-                    typename T::vec4 g = {(elem)quick_gelu(v[0]), (elem)quick_gelu(v[1]), (elem)quick_gelu(v[2]), (elem)quick_gelu(v[3])};
+                    typename T::vec4 g = {round_to<elem>(quick_gelu(v[0])), round_to<elem>(quick_gelu(v[1])), round_to<elem>(quick_gelu(v[2])), round_to<elem>(quick_gelu(v[3]))};
                     *(typename T::vec4*)((elem*)p.out1 + orow * p.ldo1 + n) = g;
                 }
             } else if constexpr (EPI == EPI_RESIDUAL) {
@@ -212,11 +212,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
                 if (p.gelu_q8) {
                     const uint32_t w = *(const uint32_t*)((const char*)p.aux + orow * p.ldaux + n);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = (elem)(v[c] * gelu_grad_from_q8(w, c));
+                    for (int c = 0; c < 4; ++c) o[c] = round_to<elem>(v[c] * gelu_grad_from_q8(w, c));
                 } else {
                     const typename T::vec4 u = *(const typename T::vec4*)((const elem*)p.aux + orow * p.ldaux + n);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = (elem)(v[c] * quick_gelu_grad((float)u[c]));
+                    for (int c = 0; c < 4; ++c) o[c] = round_to<elem>(v[c] * quick_gelu_grad((float)u[c]));
                 }
                 *(typename T::vec4*)((elem*)p.out0 + orow * p.ldo0 + n) = o;
             } else if constexpr (EPI == EPI_PATCH) {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         *(f32x4*)((float*)out + m * ldo + n) = v;
     } else {
         using elem = typename T::elem;
-        typename T::vec4 o = {(elem)v[0], (elem)v[1], (elem)v[2], (elem)v[3]};
+        typename T::vec4 o = {round_to<elem>(v[0]), round_to<elem>(v[1]), round_to<elem>(v[2]), round_to<elem>(v[3])};
         *(typename T::vec4*)((elem*)out + m * ldo + n) = o;
     }
 }
@@ -363,6 +363,7 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const Gemm
     GemmArgs b = a;
     if (variant & 0x100) b.flags |= 1;
     if (variant & 0x200) b.flags |= 2;  // gemm_pp: no half tiles in the last wave
+    b.flags |= ((variant >> 10) & 3) << 4;  // gemm_pp timing-only ablations (bits 10, 11 of the knob): no LDS fragment reads / no operand DMA
     b.flags |= ((variant >> 12) & 0xff) << 8;  // bits 12..19 of the knob: column-tile group width GN of gemm_pp (0 = default)
     // default: the persistent ping-pong kernel for the big GEMMs whose epilogue needs no operand load besides bias / u
     if (gemm_uses_pp(epi, a, o.variant)) return launch_gemm_pp(dtype, epi, b, s, o);

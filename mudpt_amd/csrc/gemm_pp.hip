@@ -54,7 +54,9 @@ constexpr int EPI_GELU_BWD_Q8 = 103;  // EPI_GELU_BWD reading such codes from au
 // 64 KiB per stage, 32 matrix instructions of twice the length per wave: the same pipe time, DMA volume, LDS image, swizzle and vmcnt
 // accounting as an fp16 step.  Both low buffers have the row stride of their T counterparts in bytes, so only the buffer descriptors change
 // between the passes.
-template <typename T, int EPI, bool F8 = false, int ST = 0, int LD = 0>
+// ABL: timing-only ablations of the K loop (WRONG results; tools/gemm_bench.py --variants 1024,2048,3072): bit 0 = no fragment reads from LDS
+// (the MFMAs run on whatever the registers hold), bit 1 = no operand DMA.  Where the K-step's 1.56 us go: DESIGN.md 4.1.
+template <typename T, int EPI, bool F8 = false, int ST = 0, int LD = 0, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int ntiles, int rem_half) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     };
     // issue unit u of the next step into LDS stage `stage`
     auto issue = [&](int u, int stage) {
+        if constexpr (ABL & 2) return;
         const bool isA = (u == 0 || u == 3);
         const int base = isA ? n_baseA : n_baseB;
         char* dst = smem + stage * STAGE + (isA ? 0 : BOFF);
@@ -219,6 +222,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     // or the ONE 8-register operand of an e4m3 step -- kept as 8-register tuples so that the latter needs no copies
     typedef __attribute__((ext_vector_type(4))) int i32x4;
     i32x8 af[4], bf[4];
+    if constexpr (ABL & 1) {  // defined operands for the timing-only build
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { af[i] = i32x8{lane, 1, 2, 3, 4, 5, 6, 7} * 0x3c003c00; bf[i] = i32x8{7, 6, 5, 4, 3, 2, 1, lane} * 0x3c003c00; }
+    }
     auto half = [](const i32x8& v, int ks) -> vec8 {
         return __builtin_bit_cast(vec8, ks ? __builtin_shufflevector(v, v, 4, 5, 6, 7) : __builtin_shufflevector(v, v, 0, 1, 2, 3));
     };
@@ -246,11 +253,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
         __builtin_amdgcn_sched_barrier(0);
     };
     auto read_a = [&](const char* st, int i0) {
+        if constexpr (ABL & 1) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             af[i] = __builtin_shufflevector(*(const i32x4*)(st + a_base + (i0 + i) * 2048 + ca), *(const i32x4*)(st + a_base + (i0 + i) * 2048 + cb), 0, 1, 2, 3, 4, 5, 6, 7);
     };
     auto read_b = [&](const char* st, int j0) {
+        if constexpr (ABL & 1) return;
 #pragma unroll
         for (int j = j0; j < j0 + 2; ++j)
             bf[j] = __builtin_shufflevector(*(const i32x4*)(st + b_base + j * BJ + ca), *(const i32x4*)(st + b_base + j * BJ + cb), 0, 1, 2, 3, 4, 5, 6, 7);
@@ -327,7 +336,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                         __builtin_amdgcn_raw_buffer_store_b128(q, rsOut0, row_off(i, p.ldo0, 1, n), 0, ST);
                     } else {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) { o0[c] = (elem)acc[i][0][c]; o0[4 + c] = (elem)acc[i][1][c]; o1[c] = (elem)acc[i][2][c]; o1[4 + c] = (elem)acc[i][3][c]; }
+                        for (int c = 0; c < 4; ++c) {  // round_to: the conversion rounds the fp32 value (no fused multiply-convert; common.h)
+                            o0[c] = round_to<elem>(acc[i][0][c]); o0[4 + c] = round_to<elem>(acc[i][1][c]);
+                            o1[c] = round_to<elem>(acc[i][2][c]); o1[4 + c] = round_to<elem>(acc[i][3][c]);
+                        }
                         const int off = row_off(i, p.ldo0, 2, n);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut0, off, 0, ST);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsOut0, off, 16, ST);
@@ -335,8 +347,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
                     if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_Q8) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            o0[c] = (elem)quick_gelu(acc[i][0][c]); o0[4 + c] = (elem)quick_gelu(acc[i][1][c]);
-                            o1[c] = (elem)quick_gelu(acc[i][2][c]); o1[4 + c] = (elem)quick_gelu(acc[i][3][c]);
+                            o0[c] = round_to<elem>(quick_gelu(acc[i][0][c])); o0[4 + c] = round_to<elem>(quick_gelu(acc[i][1][c]));
+                            o1[c] = round_to<elem>(quick_gelu(acc[i][2][c])); o1[4 + c] = round_to<elem>(quick_gelu(acc[i][3][c]));
                         }
                         const int off1 = row_off(i, p.ldo1, 2, n);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsOut1, off1, 0, ST);
@@ -491,10 +503,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p, int ntn, int n
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the second group's extra barrier
 }
 
-template <typename T, int EPI, bool F8 = false, int ST = 0, int LD = 0>
+template <typename T, int EPI, bool F8 = false, int ST = 0, int LD = 0, int ABL = 0>
 static int launch_pp(const GemmArgs& a, hipStream_t s, const GemmOpts& o) {
     constexpr int lds = 2 * 65536;
-    auto kern = gemm_pp_kernel<T, EPI, F8, ST, LD>;
+    auto kern = gemm_pp_kernel<T, EPI, F8, ST, LD, ABL>;
     static PerDevice pd;
     const int dev = current_device();
     if (!pd.done[dev]) {
@@ -533,6 +545,15 @@ static int launch_pp_t(int epi, const GemmArgs& a, hipStream_t s, const GemmOpts
             }
             set_error("gemm_pp: epilogue %d is not built with the e4m3 second pass", epi);
             return MUDPT_ERR_ARG;
+        }
+    }
+    if constexpr (T::id == DT_BF16) {  // timing-only ablations (flags bits 4, 5), bf16 store epilogue only
+        if (epi == EPI_STORE && (a.flags & 0x30)) {
+            switch ((a.flags >> 4) & 3) {
+                case 1: return launch_pp<T, EPI_STORE, false, 0, 0, 1>(a, s, o);
+                case 2: return launch_pp<T, EPI_STORE, false, 0, 0, 2>(a, s, o);
+                default: return launch_pp<T, EPI_STORE, false, 0, 0, 3>(a, s, o);
+            }
         }
     }
     switch (epi) {

@@ -129,6 +129,36 @@ def test_gemm_epilogues(lib, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gemm_rows_do_not_depend_on_the_kernel_that_ran_them(lib, dtype):
+    """A row of a GEMM must come out bit-identical whichever kernel ran the shape -- the small-tile kernel (64 x 64 or 128 x 128 tiles) or the
+    persistent one: every kernel contracts k in the same order, and (round 4) every T conversion of an epilogue rounds the fp32 VALUE
+    (common.h round_to: with -ffp-contract=fast the compiler folded the QuickGELU multiply into the conversion in one kernel and not in the
+    other, one ulp apart).  That is what makes a trimmed / bucketed text tower equal the untrimmed one (tests/test_manyclass_gpu.py).
+    The text tower's shapes at 208 class prompts: 5 408 rows (trimmed) against 16 016 (untrimmed)."""
+    dt, tt = DT[dtype]
+    M1, M0 = 5408, 16016
+    g = torch.Generator().manual_seed(11)
+    for name, N, K, epi in (("qkv", 1536, 512, 0), ("out", 512, 512, 5), ("fc", 2048, 512, 1), ("proj", 512, 2048, 5), ("dgelu", 2048, 512, 3), ("dfc", 512, 2048, 0)):
+        A = torch.randn(M0, K, generator=g).to(tt).cuda()
+        B = (torch.randn(N, K, generator=g) * K ** -0.5).to(tt).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        auxf = torch.randn(M0, N, generator=g).to(tt).cuda()
+        res = {}
+        for M in (M1, M0):
+            out0 = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi == 5 else tt)
+            out1 = torch.zeros(M, N, device="cuda", dtype=tt) if epi == 1 else None
+            gemm(lib, dt, epi, A[:M], B, bias=bd_or_none(bias, epi), out0=out0, out1=out1, aux=auxf[:M] if epi == 3 else None)
+            res[M] = (out0[:M1].clone(), out1[:M1].clone() if out1 is not None else None)
+        assert torch.equal(res[M1][0], res[M0][0]), name
+        if epi == 1:
+            assert torch.equal(res[M1][1], res[M0][1]), name
+
+
+def bd_or_none(bias, epi):
+    return None if epi == 3 else bias
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(804, 768, 3072), (804, 768, 2304), (450, 512, 2048), (201, 768, 3072), (1000, 768, 1536)])
 def test_gemm_split_k(lib, dtype, shape):
     """Small grids with a long contraction (the reference's training batch of 4: M = 804) split K over up to 4 slices whose fp32 partials are
