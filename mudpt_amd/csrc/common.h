@@ -124,15 +124,31 @@ __device__ inline uint32_t pack_lo8(float a, float b, float c, float d) {
     return (uint32_t)w;
 }
 
+// Wave-wide reductions on the DPP path (round 4): a butterfly inside each row of 16 lanes (quad_perm, row_half_mirror, row_mirror), the
+// two row broadcasts that carry the partial results into the last row, and a v_readlane of lane 63 -- six single-cycle-issue VALU
+// operations with no LDS round trip.  The __shfl_xor form they replace lowers to six DEPENDENT ds_bpermute_b32 (~60 clocks each through
+// the LDS crossbar): two such chains sat between the load and the store phase of every LayerNorm row.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ inline float dpp_mov(float v, float old) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xb1>(v, 0.f);         // quad_perm [1, 0, 3, 2]
+    v += dpp_mov<0x4e>(v, 0.f);         // quad_perm [2, 3, 0, 1]
+    v += dpp_mov<0x141>(v, 0.f);        // row_half_mirror
+    v += dpp_mov<0x140>(v, 0.f);        // row_mirror: every lane of a row holds the row's sum
+    v += dpp_mov<0x142, 0xa>(v, 0.f);   // row_bcast:15 into rows 1, 3
+    v += dpp_mov<0x143, 0xc>(v, 0.f);   // row_bcast:31 into rows 2, 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xb1>(v, v));
+    v = fmaxf(v, dpp_mov<0x4e>(v, v));
+    v = fmaxf(v, dpp_mov<0x141>(v, v));
+    v = fmaxf(v, dpp_mov<0x140>(v, v));
+    v = fmaxf(v, dpp_mov<0x142, 0xa>(v, v));
+    v = fmaxf(v, dpp_mov<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Bijective XCD-aware remap of a 1-D grid: blocks that share an XCD (bid % 8) get one contiguous
