@@ -54,8 +54,8 @@ extern "C" {
  *   vision tower  remainder as e4m3, contracted against an e4m3 copy of the weights on the MX-scaled fp8 matrix instruction
  *                 (v_mfma_scale_f32_16x16x128_f8f6f4: twice the fp16 rate, so the second pass costs half of the first), pixels included;
  *                 attention in fp16.
- * Measured against the reference's own logits at scale 100: <= 3.5e-4 (ViT-B/16; 8e-5 ViT-L/14@336), 1.27x the bf16 step.  Knobs
- * (mudpt_model_set): vis_exact_attn = 1 -> 8e-5; vis_lo = 1 + vis_exact_attn = 1 -> round 3's "exact" mode, 2.5e-5 at 1.56x.  The
+ * Measured against the reference's own logits at scale 100: <= 3.5e-4 (ViT-B/16; 1.2e-4 ViT-L/14@336), 1.26x the bf16 step.  Knobs
+ * (mudpt_model_set): vis_exact_attn = 1 -> 8e-5; vis_lo = 1 + vis_exact_attn = 1 -> round 3's "exact" mode, 2e-5 at 1.6x.  The
  * backward is the MUDPT_F16 one with fp16 activation gradients.  Per-site ablation: DESIGN.md 2. */
 #define MUDPT_F32 2
 
