@@ -747,10 +747,13 @@ __global__ __launch_bounds__(NC * 64 * W2) void attn_bwd_fused_kernel(AttnArgs p
 // (252 us with the workgroups' starts staggered; its dQ phases keep only 8 and 5 of the 14 waves busy and the persistent
 // workgroups load and compute in lockstep), and fully unrolled loops with immediate LDS offsets (214 us: not the instruction count).
 // DS image: panels of 32 queries, [panel][key][32 queries] with 64-byte rows; the two 32-byte halves of a row are swapped for keys
-// with bit 2 set, which makes the transposed 4-key x 16-query block reads conflict-free.
+// with bit 2 set, which makes the transposed 4-key x 16-query block reads conflict-free; inside a half the four 8-byte units (4 queries
+// each) are rotated by two for keys with bit 3 set (round 4): the sweep's 8-byte writes of keys c and c + 8 of a wave otherwise fall on
+// the same banks (2-way conflicts on every dS store: SQ_LDS_BANK_CONFLICT was 18 % of the LDS pipe's active cycles); the block reads
+// stay conflict-free (a 16-lane group reads four keys that share bits 2 and 3).
 template <int LP>
 __device__ inline int ds_off(int key, int q) {  // byte offset of element (key, q); q & 3 == 0 for the 8-byte accesses
-    return (q >> 5) * (LP * 64) + key * 64 + ((((q >> 4) & 1) ^ ((key >> 2) & 1)) << 5) + (q & 15) * 2;
+    return (q >> 5) * (LP * 64) + key * 64 + ((((q >> 4) & 1) ^ ((key >> 2) & 1)) << 5) + ((((q & 15) >> 2) ^ (((key >> 3) & 1) << 1)) << 3) + (q & 3) * 2;
 }
 
 template <typename T, int NC>

@@ -112,3 +112,37 @@ def test_full_size_batch_properties_bf16():
         assert rms > 0, k
         assert (a - b).pow(2).mean().sqrt().item() <= 0.1 * rms, k
     m.close()
+
+
+def test_split_operand_knobs_are_refused_where_the_buffers_do_not_exist():
+    """The split-operand knobs (include/mudpt.h MUDPT_F32) only exist where the mode keeps low halves: a bf16 handle has none, an fp16 handle
+    only in its text tower, and e4m3 remainders need the e4m3 weight copies (vision tower of the parity mode)."""
+    from mudpt_amd import capi
+    cfg = O.TINY
+    frozen = O.make_frozen_state(cfg, 61)
+    tok = O.synthetic_tokens(cfg, 3).long()
+    params = O.make_trainable_state(cfg, 62)
+    m = build(cfg, frozen, tok, params, "bf16", 1)
+    for knob, v in (("vis_lo", 1), ("txt_lo", 1), ("vis_exact_attn", 1), ("txt_exact_attn", 1)):
+        with pytest.raises(capi.MudptError):
+            m.set_knob(knob, v)
+    m.set_knob("vis_lo", 0)   # switching OFF is always fine
+    m.close()
+    m = build(cfg, frozen, tok, params, "fp16", 1)
+    m.set_knob("txt_lo", 0)
+    m.set_knob("txt_lo", 1)
+    with pytest.raises(AssertionError):   # e4m3 remainders: no e4m3 weights in the text tower (bad argument)
+        m.set_knob("txt_lo", 2)
+    with pytest.raises(capi.MudptError):
+        m.set_knob("vis_lo", 2)
+    with pytest.raises(capi.MudptError):
+        m.set_knob("txt_exact_attn", 1)  # the fp32 attention forward belongs to the parity mode
+    m.close()
+    m = build(cfg, frozen, tok, params, "fp32", 1)
+    for knob, v in (("vis_lo", 0), ("vis_lo", 1), ("vis_lo", 2), ("vis_sites", 12), ("txt_sites", 15), ("vis_exact_attn", 1), ("txt_exact_attn", 0), ("txt_lo", 0)):
+        m.set_knob(knob, v)
+    with pytest.raises(AssertionError):
+        m.set_knob("txt_lo", 2)
+    g = torch.Generator().manual_seed(63)
+    assert torch.isfinite(m(torch.randn(1, 3, cfg.image_size, cfg.image_size, generator=g))).all()  # and the handle still runs with the knobs moved
+    m.close()
