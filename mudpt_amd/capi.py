@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MUDPT_LIB") or os.path.join(HERE, "lib", "libmudpt_hip.so")  # MUDPT_LIB: A/B runs of two builds on one box
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "mudpt.h")
 
-BF16, F16, F32 = 0, 1, 2  # F32: the exact mode (include/mudpt.h MUDPT_F32)
+BF16, F16, F32 = 0, 1, 2  # F32: the parity mode (include/mudpt.h MUDPT_F32)
 VARIANT_MUDPT, VARIANT_COCOOP = 0, 1
 ABI_VERSION = 6
 EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD, EPI_PATCH, EPI_STORE_F32 = range(6)

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NC * 64) void attn_bwd_dq_kernel(AttnArgs p, const 
     const size_t ld = (size_t)3 * HD;
     const elem* base = (const elem*)p.qkv + (size_t)b * L * ld + hd * 64;
     const elem* dO = (const elem*)p.dout + (size_t)b * L * HD + hd * 64;
-    const size_t ldof = p.ld_out ? (size_t)p.ld_out : (size_t)HD;  // the forward output may be the hi half of a [hi | lo] row
+    const size_t ldof = p.ld_out ? (size_t)p.ld_out : (size_t)HD;  // (a caller may keep the forward output in rows wider than H * 64)
     const elem* Of = (const elem*)fwd_out + (size_t)b * L * ldof + hd * 64;
 
     struct Frags { vec8 q0, q1, g0, g1, o0, o1; };
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(NC * 64 * W2) void attn_bwd_fused_kernel(AttnArgs p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HD = p.H * 64, L = p.L;
     const size_t ld = (size_t)3 * HD;
-    const size_t ldof = p.ld_out ? (size_t)p.ld_out : (size_t)HD;  // the forward output may be the hi half of a [hi | lo] row
+    const size_t ldof = p.ld_out ? (size_t)p.ld_out : (size_t)HD;  // (a caller may keep the forward output in rows wider than H * 64)
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.qkv), 0, (int)((size_t)p.B * L * ld * 2), 0x00020000);
     const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dout), 0, (int)((size_t)p.B * L * HD * 2), 0x00020000);
     // lane part of a DMA source: row (lane >> 3) of an 8-row group, 16-byte chunk (lane & 7) ^ (row & 7) (the LDS slot is lane-linear)

@@ -71,7 +71,7 @@ int launch_patchify(int dtype, const float* images, void* patches, int B, int S,
     return MUDPT_OK;
 }
 
-// Split-operand form (exact mode): row = [hi | lo] of 2 ldk elements, lo = pixel - (float)hi; one thread per pixel slot.
+// Split-operand form (parity mode, common.h LoMode): hi = T(pixel) to `out`, the remainder pixel - hi to `out_lo` as T or as e4m3 bytes; four pixel slots per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_split_kernel(const float* __restrict__ img, typename T::elem* __restrict__ out, void* __restrict__ out_lo, int lo_mode,
                                                              int B, int S, int p, int ldk) {

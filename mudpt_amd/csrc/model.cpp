@@ -276,7 +276,7 @@ static int prof_next(mudpt_model* m, int cls, double work, LaunchProf* out) {
 // Every MFMA GEMM of the path goes through here; with profiling on, the launch is bracketed by HIP events on
 // the launch stream and its algorithmic FLOPs (2 M N K) are recorded.
 // bwd: a GEMM of the backward pass.  Those may always split K; a FORWARD GEMM only where the caller allows it (fwd_split: the vision
-// tower's out_proj / c_proj outside the exact mode) and its grid is at most kFwdSplitTiles 64 x 64 tiles (ViT-B: up to 8 images -- the
+// tower's out_proj / c_proj, never with split operands) and its grid is at most kFwdSplitTiles 64 x 64 tiles (ViT-B: up to 8 images -- the
 // reference's own training batch of 4, where c_proj's 48-step chain on 156 workgroups was the longest kernel of the step).  The text
 // tower never splits, forward or backward (its call sites pass bwd = !t.causal): its features are bit-identical and its gradients equal to
 // the order of the fp32 sums over classes however the class prompts are bucketed (a tested property; a split decision that depends on the
@@ -327,7 +327,7 @@ static int attn_call(mudpt_model* m, const Tower& t, const AttnArgs& a0, bool bw
     // executed MFMA FLOPs: forward S = QK^T and PV (2 products of 2 L^2 64 each per head); backward 7 products (dQ sweep: S, dP, dQ;
     // dK/dV sweep: S, dP, dV, dK); the causal tower does about half of each
     const double prod = 2.0 * a.L * (double)a.L * 64.0 * a.H * a.B * (a.causal ? 0.5 : 1.0);
-    const bool exact_fwd = !bwd && a.qkv32;  // exact mode: fp32 matrix-core FLOPs are not counted as executed bf16 / fp16 MFMA work
+    const bool exact_fwd = !bwd && a.qkv32;  // fp32 attention forward: fp32 matrix-core FLOPs are not counted as executed bf16 / fp16 MFMA work
     if (m->prof && !a.sel_rows && !exact_fwd) m->exec_flop += (bwd ? 7.0 : 2.0) * prod;
     if (exact_fwd) return launch_attn_fwd_exact(a, s);
     if (!prof_big(m, t, a.B * a.L) || a.sel_rows) return bwd ? launch_attn_bwd(m->dtype, a, s) : launch_attn_fwd(m->dtype, a, s);
@@ -732,7 +732,7 @@ extern "C" int mudpt_set_class_prompts(mudpt_model* m, const float* emb, const i
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const size_t per_row = tower_bytes_per_row(m->txt), budget = (size_t)((double)free_b * 0.6);
         size_t rows_max = budget / per_row;
-        // the widest row of a pass (QuickGELU(u) as a split [hi | lo] operand: 8 d elements) stays inside the kernels' 32-bit byte offsets
+        // the widest row of a pass (QuickGELU(u) and its low half: 2 x 8 d bytes) stays inside the kernels' 32-bit byte offsets
         const size_t rows_cap = (size_t)0x7fffffff / ((size_t)16 * d) - 1;
         if (rows_max > rows_cap) rows_max = rows_cap;
         chunk = rows_max / (C * Le);

@@ -227,7 +227,10 @@ def _e4m3_weights(lib, W):
 
 @pytest.mark.parametrize("lo_mode", [1, 2])
 @pytest.mark.parametrize("M,N,K,epi", [(804, 768, 768, 5), (99, 512, 2048, 2), (804, 3072, 768, 1), (6000, 3072, 1536, 1), (22000, 2048, 1024, 1),
-                                        (51456 // 4, 2304, 768, 0), (13000, 768, 3072, 5), (700, 192, 128, 0)])
+                                        (51456 // 4, 2304, 768, 0), (13000, 768, 3072, 5), (700, 192, 128, 0),
+                                        # K = 640 (ViT-L/14's padded patch rows): 10 + 5 K-steps per tile, an odd count -- the LDS stage of a tile's first
+                                        # step alternates from tile to tile; N = 1008: a ragged last column tile; both on the persistent kernel
+                                        (30000, 1024, 640, 5), (20000, 1008, 1024, 0)])
 def test_split_operand_gemm(lo_mode, M, N, K, epi):
     """A forward GEMM of a split tower: first pass hi . W^T, second pass over the low half -- fp16 remainders against the same W (lo_mode 1)
     or e4m3 remainders against the e4m3 weights on the MX-scaled fp8 matrix instruction (lo_mode 2) -- through the small-tile kernel and
