@@ -157,25 +157,23 @@ __device__ inline float group_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// One 16-query block of one (sequence, head) pair: scores, softmax, P.V, store.  q0 / q1 = this lane's Q fragments.
+// One 16-query block of one (sequence, head) pair in two halves: scores + softmax numerators (fwd_scores), P.V + store (fwd_pv_store).
+// q0 / q1 = this lane's Q fragments.  S holds the scores, then the UNNORMALISED probabilities exp(s - m); m = row maximum (raw scores), l = row sum.
+// Key tiles that lie wholly beyond L are skipped (L = 201: tile 13 of 14; P = 0 there), and only a tile that straddles L reads the key mask
+// (round 4: the 14 mask reads were a quarter of this half's LDS instructions).
 template <typename T, int NC, bool CAUSAL>
-__device__ inline void fwd_qblock(const AttnArgs& p, const typename T::elem* Ks, const typename T::elem* Vs, const float* kmask, int pair,
-                                  int qb, typename T::vec8 q0, typename T::vec8 q1, int lane) {
+__device__ inline void fwd_scores(int L, const typename T::elem* Ks, const float* kmask, int qb, typename T::vec8 q0, typename T::vec8 q1, int lane,
+                                  f32x4 (&S)[2 * NC], float& m, float& l) {
     using A = Attn<T>;
-    using elem = typename T::elem;
-    using vec8 = typename T::vec8;
-    constexpr int Lp = NC * 32;
-    const int g = lane >> 4, c = lane & 15, L = p.L, HD = p.H * 64;
+    const int g = lane >> 4, c = lane & 15;
     const int q = qb * 16 + c;
     const int nkc = CAUSAL ? (qb >> 1) + 1 : NC;  // 32-key chunks that hold a visible key
-
-    f32x4 S[2 * NC];
-    float m = -INFINITY;
+    m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 2 * NC; ++kt) {
         S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (kt < 2 * nkc) {
-            S[kt] = *(const f32x4*)(kmask + kt * 16 + 4 * g);  // padding keys start (and stay) at -inf: no per-element mask
+        if (kt < 2 * nkc && (kt < 2 * NC - 2 || kt * 16 < L)) {  // 32 (NC - 1) < L <= 32 NC (the dispatcher's choice of NC): only the last two tiles can hold padding
+            if (kt >= 2 * NC - 2 && kt * 16 + 16 > L) S[kt] = *(const f32x4*)(kmask + kt * 16 + 4 * g);  // padding keys start (and stay) at -inf: no per-element mask
             S[kt] = T::mfma16(A::rows(Ks, kt * 16, 0, lane), q0, S[kt]);
             S[kt] = T::mfma16(A::rows(Ks, kt * 16, 1, lane), q1, S[kt]);
             if constexpr (CAUSAL) {
@@ -189,10 +187,10 @@ __device__ inline void fwd_qblock(const AttnArgs& p, const typename T::elem* Ks,
     }
     m = group_max(m);
     const float nm = -m * SC;
-    float l = 0.f;
+    l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2 * NC; ++kt)
-        if (kt < 2 * nkc) {
+        if (kt < 2 * nkc && (kt < 2 * NC - 2 || kt * 16 < L)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][r], SC, nm));
@@ -201,7 +199,19 @@ __device__ inline void fwd_qblock(const AttnArgs& p, const typename T::elem* Ks,
             }
         }
     l = group_sum(l);
+}
 
+template <typename T, int NC, bool CAUSAL>
+__device__ inline void fwd_pv_store(const AttnArgs& p, const typename T::elem* Vs, int pair, int qb, const f32x4 (&S)[2 * NC], float m, float l, int lane) {
+    using A = Attn<T>;
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    constexpr int Lp = NC * 32;
+    const int g = lane >> 4, c = lane & 15, L = p.L, HD = p.H * 64;
+    const int q = qb * 16 + c;
+    const int nkc = CAUSAL ? (qb >> 1) + 1 : NC;
+    // (Round 4, measured and not kept: the row sums as a fifth "d tile" of ones on the matrix pipe instead of 56 VALU adds: 90 vs 77 us -- seven
+    // dependent MFMAs and 8 more registers -- and a sum of ROUNDED probabilities misses the 1e-3 bound on lse in bf16.)
     f32x4 O[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -223,6 +233,15 @@ __device__ inline void fwd_qblock(const AttnArgs& p, const typename T::elem* Ks,
         else A::store_t((elem*)p.out + off, O, 1.f / l, lane);
     }
     if (g == 0 && p.lse) p.lse[(size_t)pair * Lp + q] = q < L ? m * 0.125f + __logf(l) : 0.f;
+}
+
+template <typename T, int NC, bool CAUSAL>
+__device__ inline void fwd_qblock(const AttnArgs& p, const typename T::elem* Ks, const typename T::elem* Vs, const float* kmask, int pair,
+                                  int qb, typename T::vec8 q0, typename T::vec8 q1, int lane) {
+    f32x4 S[2 * NC];
+    float m, l;
+    fwd_scores<T, NC, CAUSAL>(p.L, Ks, kmask, qb, q0, q1, lane, S, m, l);
+    fwd_pv_store<T, NC, CAUSAL>(p, Vs, pair, qb, S, m, l, lane);
 }
 
 // Causal forward (text tower): one workgroup per (sequence, head) pair, several per CU.  The persistent form below pays a
@@ -267,6 +286,10 @@ __global__ __launch_bounds__(NC * 64) void attn_fwd_pair_kernel(AttnArgs p) {
 // MFMA-bound: the load and compute phases of a CU's two workgroups rarely overlapped.)
 // Rows >= L of an image hold the next sequence's rows (finite values; zeros past the end of the tensor through the buffer
 // descriptor): padded keys are masked by the -inf initial value of their score accumulators, so P = 0 multiplies them.
+// Round 4, measured and not kept: "late" waves -- every other wave of a SIMD one phase group behind (P.V of the PREVIOUS pair, then scores +
+// softmax of the current one, a third V image) so that one half's exponentials fall on the other half's LDS phases: 85.6 vs 75.2 us.  Nor is
+// it the fourth block of the one SIMD that gets 4 of the 13 query blocks: a timing run without block 12 took 70.0 vs 76.6 us, its share of the
+// work.  The time follows the instruction count (VALU ~ 1 900 cycles per block, half of them the 56 quarter-rate exponentials).
 template <typename T, int NC, bool CAUSAL>
 __global__ __launch_bounds__(NC * 128) void attn_fwd_kernel(AttnArgs p, int npairs) {
     using A = Attn<T>;
@@ -828,6 +851,7 @@ __global__ __launch_bounds__(NC * 128) void attn_bwd_sweep_kernel(AttnArgs p, co
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
+        // (round 4: skipping the last query tile when it lies wholly beyond L -- tile 13 of 14 at L = 201 -- behind a uniform branch: 215.5 vs 212.0 us)
         for (int qc = 0; qc < NC; ++qc) {  // fully unrolled: every LDS address becomes a loop-invariant lane base + an immediate offset
             f32x4 P[2], dS[2];
 #pragma unroll

@@ -44,8 +44,8 @@ def main():
         lse = torch.zeros(B, H, Lp, device="cuda")
         delta = torch.zeros(B, H, Lp, device="cuda")
 
-        def fwd():
-            assert lib.mudpt_attention_fwd(0, P(qkv), P(out), P(lse), B, L, H, causal, None) == 0
+        def fwd(form=0):
+            assert lib.mudpt_attention_fwd(0, P(qkv), P(out), P(lse), B, L, H, causal | form, None) == 0
 
         def bwd(form=0):
             assert lib.mudpt_attention_bwd(0, P(qkv), P(out), P(dout), P(lse), P(delta), P(dqkv), B, L, H, causal | form, None) == 0
