@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "lib", "libmudpt_hip.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_w4.hip", "attention.hip", "attention_single.hip", "attention_exact.hip", "attention_resident.hip", "layernorm.hip", "elementwise.hip", "head.hip", "model.cpp"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "attention.hip", "attention_single.hip", "attention_exact.hip", "attention_resident.hip", "layernorm.hip", "elementwise.hip", "head.hip", "model.cpp"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "mudpt.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 EXTRA_FLAGS = {"attention_resident.hip": ["-fno-slp-vectorize"]}  # why: the header of that file

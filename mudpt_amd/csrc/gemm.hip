@@ -364,13 +364,9 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const Gemm
     if (variant & 0x100) b.flags |= 1;
     if (variant & 0x200) b.flags |= 2;  // gemm_pp: no half tiles in the last wave
     b.flags |= ((variant >> 10) & 3) << 4;  // gemm_pp timing-only ablations (bits 10, 11 of the knob): no LDS fragment reads / no operand DMA
-    b.flags |= ((variant >> 21) & 1) << 6;  // gemm_w4 only (bit 21): no K-step barrier
     b.flags |= ((variant >> 12) & 0xff) << 8;  // bits 12..19 of the knob: column-tile group width GN of gemm_pp (0 = default)
     // default: the persistent ping-pong kernel for the big GEMMs whose epilogue needs no operand load besides bias / u
-    if (gemm_uses_pp(epi, a, o.variant)) {
-        if ((variant & 0x100000) && epi == EPI_STORE && a.lo_mode == LO_NONE) return launch_gemm_w4(dtype, epi, b, s, o);  // A/B: the four-wave kernel
-        return launch_gemm_pp(dtype, epi, b, s, o);
-    }
+    if (gemm_uses_pp(epi, a, o.variant)) return launch_gemm_pp(dtype, epi, b, s, o);
     if (const int S = split_k_slices(epi, a, o); S > 1) {
         GemmArgs q = b;
         q.bias = nullptr; q.out0 = o.scratch; q.ldo0 = a.N; q.ksplit = a.K / S; q.split_stride = (size_t)a.M * a.N;

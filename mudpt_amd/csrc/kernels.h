@@ -53,7 +53,6 @@ struct GemmOpts {
 int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o = GemmOpts());
 bool gemm_uses_pp(int epi, const GemmArgs& a, int variant = 0);  // true if launch_gemm dispatches to gemm_pp_kernel
 int launch_gemm_pp(int dtype, int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o);  // persistent 256x256 ping-pong kernel (gemm_pp.hip)
-int launch_gemm_w4(int dtype, int epi, const GemmArgs& a, hipStream_t s, const GemmOpts& o);  // four-wave form of it (gemm_w4.hip; knob bit 20)
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (fp32 statistics, eps 1e-5; clip/model.py:164-170).
