@@ -20,18 +20,23 @@ namespace mudpt {
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int NS = 2>
+// BK = 128 (round 4, small grids): 256-byte LDS rows, a wave instruction fills 4 of them, chunk c of row r sits in slot c ^ (r & 15) -- half the
+// K-steps, i.e. half the wait -> barrier -> fragment-read -> MFMA chains of a workgroup that has the CU almost to itself.  No split operand.
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int NS = 2, int BK = 64>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
     constexpr int NW = WM * WN;
-    constexpr int BK = 64;
+    static_assert(BK == 64 || BK == 128, "K-tile");
+    constexpr int ROWB = BK * 2;      // bytes of an LDS row
+    constexpr int RPI = 1024 / ROWB;  // rows a wave's DMA instruction fills
+    constexpr int CPR = ROWB / 16;    // 16-byte chunks per row
     constexpr int TM = BM / WM / 16;  // 16-row sub-tiles per wave along M
     constexpr int TN = BN / WN / 16;
-    constexpr int IA = BM / 8 / NW;   // global_load_lds instructions per wave for the A tile
-    constexpr int IB = BN / 8 / NW;
-    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over the waves");
+    constexpr int IA = BM / RPI / NW;   // global_load_lds instructions per wave for the A tile
+    constexpr int IB = BN / RPI / NW;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must split over the waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -51,21 +56,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     const elem* __restrict__ Bw = (const elem*)p.B + (size_t)kz * kspan;
 
     // per-lane source pointers (k offset advances by BK per tile); rows clamped at the ragged edge
-    const int srow = lane >> 3;                       // row inside the 8-row group this lane fills
-    const int schunk = (lane & 7) ^ srow;             // swizzled source chunk for LDS slot (lane & 7)
+    const int srow = lane / CPR;                      // row inside the RPI-row group this lane fills
     const elem* asrc[IA];
     const elem* bsrc[IB];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-        int r = m0 + (wave + NW * i) * 8 + srow;
+        const int tr = (wave + NW * i) * RPI + srow;  // row of the tile; swizzled source chunk for LDS slot lane % CPR
+        int r = m0 + tr;
         r = r < p.M ? r : p.M - 1;
-        asrc[i] = A + (size_t)r * p.lda + schunk * 8;
+        asrc[i] = A + (size_t)r * p.lda + ((lane % CPR) ^ (tr & (CPR - 1))) * 8;
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-        int r = n0 + (wave + NW * i) * 8 + srow;
+        const int tr = (wave + NW * i) * RPI + srow;
+        int r = n0 + tr;
         r = r < p.N ? r : p.N - 1;
-        bsrc[i] = Bw + (size_t)r * p.ldb + schunk * 8;
+        bsrc[i] = Bw + (size_t)r * p.ldb + ((lane % CPR) ^ (tr & (CPR - 1))) * 8;
     }
 
     // Split A operand (common.h LoMode): after the nt1 K-tiles of the first pass (hi against B) a second pass contracts the low half --
@@ -80,14 +86,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE_BYTES;
         const bool second = kt >= nt1;
-        const ptrdiff_t oa = second ? dA + (ptrdiff_t)(kt - nt1) * 128 : (ptrdiff_t)kt * 128;
-        const ptrdiff_t ob = second ? dB + (ptrdiff_t)(kt - nt1) * 128 : (ptrdiff_t)kt * 128;
+        const ptrdiff_t oa = second ? dA + (ptrdiff_t)(kt - nt1) * ROWB : (ptrdiff_t)kt * ROWB;
+        const ptrdiff_t ob = second ? dB + (ptrdiff_t)(kt - nt1) * ROWB : (ptrdiff_t)kt * ROWB;
 #pragma unroll
         for (int i = 0; i < IA; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)((const char*)asrc[i] + oa), (lptr_t)(base + (wave + NW * i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < IB; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)bsrc[i] + ob), (lptr_t)(base + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)bsrc[i] + ob), (lptr_t)(base + BM * ROWB + (wave + NW * i) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[TM][TN];
@@ -101,10 +107,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     const int fq = lane >> 4;
     int aoff[TM], boff[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) aoff[i] = (wm * (BM / WM) + i * 16 + frow) * 128;
+    for (int i = 0; i < TM; ++i) aoff[i] = (wm * (BM / WM) + i * 16 + frow) * ROWB;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) boff[j] = BM * 128 + (wn * (BN / WN) + j * 16 + frow) * 128;
-    const int sw = frow & 7;  // (row & 7): sub-tile bases are multiples of 16
+    for (int j = 0; j < TN; ++j) boff[j] = BM * ROWB + (wn * (BN / WN) + j * 16 + frow) * ROWB;
+    const int sw = frow & (CPR - 1);  // (row & (CPR - 1)): sub-tile bases are multiples of 16
 
     // NS-deep ring of stages: the loads of k-tiles kt + 1 .. kt + NS - 1 are in flight while tile kt is multiplied.  NS = 2 is the
     // plain double buffer (2 workgroups per CU hide each other's waits); NS = 4 is for grids smaller than the chip (the text
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
         __syncthreads();  // ... for every wave; and every wave is done reading the stage refilled next (read in step kt - 1)
         if (kt + NS - 1 < nt) stage((kt + NS - 1) & (NS - 1), kt + NS - 1);
         const char* base = smem + cur * STAGE_BYTES;
-        if constexpr (decltype(f8tag)::value) {
+        if constexpr (decltype(f8tag)::value && BK == 64) {
             // e4m3 tile: 128 k per row; lane (frow, fq) owns bytes 32 fq .. 32 fq + 31 of its row = chunks 2 fq, 2 fq + 1 (swizzled like every
             // tile), ONE K = 128 matrix instruction per sub-tile pair (operand pairing and block scales: tools/probes/mfma_f8_layout.py)
             const int c = ((2 * fq) ^ sw) * 16;
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
             }
         } else {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BK / 32; ++ks) {
                 const int c = ((ks * 4 + fq) ^ sw) * 16;
                 vec8 af[TM], bf[TN];
 #pragma unroll
@@ -229,10 +235,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int NS = 2>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int NS = 2, int BK = 64>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
-    constexpr int lds = NS * (BM + BN) * 64 * 2;
-    auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, NS>;
+    constexpr int lds = NS * (BM + BN) * BK * 2;
+    auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, NS, BK>;
     static PerDevice pd;
     const int dev = current_device();
     if (!pd.done[dev]) {
@@ -253,7 +259,27 @@ static inline bool small_tiles(const GemmArgs& a) {
     return t64 <= 1280 || (t64 <= 2560 && a.K <= 512);
 }
 
-// variant: tuning knob (mudpt_model_set "gemm_variant" / mudpt_gemm's last argument): 0 = default kernel choice, 1/2/4 = force a simple tile
+static int device_cus() {
+    static PerDevice pd;
+    const int dev = current_device();
+    if (!pd.done[dev]) {
+        if (hipDeviceGetAttribute(&pd.ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 256;
+        pd.done[dev] = true;
+    }
+    return pd.ncu[dev];
+}
+
+// Round 4: 128-deep K-tiles for the 64 x 64 kernel while ALL its workgroups are resident at two per CU (64 KB of LDS each) -- these grids are
+// latency chains (wait -> barrier -> fragment reads -> MFMAs per K-tile), and half as many links is what pays: qkv 804 x 2304 x 768 9.8 -> 8.6 us,
+// proj 804 x 768 x 3072 in 3 slices 15.3 -> 13.8; the text tower's 1000 x 512 x 2048 11.2 -> 10.9.  Results are bit-identical to the 64-deep form
+// (same order of the k-steps).  Grids beyond two workgroups per CU lose (fc 804 x 3072 x 768, 624 tiles: 13.7 -> 16.2): they keep 64.
+static inline bool deep_k_tiles(const GemmArgs& a, int slices, int variant) {
+    const size_t t64 = (size_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    return (variant & 0xff) != 12 && a.lo_mode == LO_NONE && (a.K / slices) % 128 == 0 && t64 * slices <= (size_t)2 * device_cus();
+}
+
+// variant: tuning knob (mudpt_model_set "gemm_variant" / mudpt_gemm's last argument): 0 = default kernel choice, 1/2/4 = force a simple tile,
+// 12 = the default choice without the 128-deep K-tiles (A/B)
 template <typename T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, int variant) {
     // Large problems that do not go to the persistent ping-pong kernel (gemm_pp.hip): 256 x 256 tile on 8 waves;
@@ -273,7 +299,8 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, int variant) {
     // tile on 4 waves with the plain double buffer wins on every shape measured (tools/gemm_bench.py --set small / text: sum of a block's
     // GEMMs 217 -> 167 us at M = 804): 32 KB of LDS lets five workgroups share a CU, and these grids are latency chains, not MFMA-bound.
     // gemm_variant 5 / 6 force the earlier 128 x 128 shallow / 128 x 64 deep forms, 9 this one (A/B runs).
-    if ((v == 0 && small_tiles(a)) || v == 9) return launch_cfg<T, 64, 64, 2, 2, EPI, 2>(a, s);
+    if (((v == 0 && small_tiles(a)) || v == 10) && deep_k_tiles(a, 1, variant)) return launch_cfg<T, 64, 64, 2, 2, EPI, 2, 128>(a, s);
+    if (((v == 0 || v == 12) && small_tiles(a)) || v == 9 || v == 10) return launch_cfg<T, 64, 64, 2, 2, EPI, 2>(a, s);
     if ((t128 <= 128 && v != 5) || v == 6) return launch_cfg<T, 128, 64, 2, 2, EPI, 4>(a, s);
     return launch_cfg<T, 128, 128, 2, 2, EPI>(a, s);
 }
@@ -314,17 +341,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // Split K for the store GEMMs whose grid is a fraction of the chip and whose contraction is long (small batches: M = B L = 804 rows at
 // the reference's training batch of 4, K = 2304 / 3072): a 128 x 64 tile per workgroup leaves 2/3 of the CUs idle while every workgroup
 // walks 36-48 K-steps.  S slices of K fill the chip; their fp32 partials go through the caller's scratch and are summed in slice order.
-static int split_k_slices(int epi, const GemmArgs& a, const GemmOpts& o) {
-    if (!(epi == EPI_STORE || epi == EPI_STORE_F32) || !o.scratch || (o.variant & 0xff) != 0 || a.lo_mode != LO_NONE) return 1;
-    static PerDevice pd;
-    const int dev = current_device();
-    if (!pd.done[dev]) {
-        if (hipDeviceGetAttribute(&pd.ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
-        pd.done[dev] = true;
-    }
+static int split_k_slices(int epi, const GemmArgs& a, const GemmOpts& o, bool& deep) {
+    deep = false;
+    const int v = o.variant & 0xff;
+    if (!(epi == EPI_STORE || epi == EPI_STORE_F32) || !o.scratch || (v != 0 && v != 12) || a.lo_mode != LO_NONE) return 1;
+    const int ncu = device_cus();
     const size_t tiles = (size_t)((a.M + 63) / 64) * ((a.N + 63) / 64);  // 64 x 64 tiles, five workgroups to a CU
-    if (tiles * 2 > (size_t)pd.ncu[dev] * 5 || a.K < 1536) return 1;
-    int S = (int)((size_t)pd.ncu[dev] * 5 / tiles);
+    if (tiles * 2 > (size_t)ncu * 5 || a.K < 1536) return 1;
+    // with 128-deep K-tiles two workgroups share a CU: three or four slices of those beat four of the 64-deep form (deep_k_tiles)
+    int S = (int)((size_t)ncu * 2 / tiles);
+    if (S > 4) S = 4;
+    while (S > 1 && (a.K % (S * 128) != 0 || a.K / S < 512)) --S;
+    if (S >= 3 && deep_k_tiles(a, S, o.variant) && (size_t)S * a.M * a.N <= o.scratch_elems) { deep = true; return S; }
+    S = (int)((size_t)ncu * 5 / tiles);
     if (S > 4) S = 4;
     while (S > 1 && (a.K % (S * 64) != 0 || a.K / S < 512)) --S;
     if ((size_t)S * a.M * a.N > o.scratch_elems) return 1;
@@ -335,7 +364,7 @@ static int split_k_slices(int epi, const GemmArgs& a, const GemmOpts& o) {
 bool gemm_uses_pp(int epi, const GemmArgs& a, int variant) {
     const bool pp_epi = epi == EPI_STORE || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32;
     const int v = variant & 0xff;
-    return (v == 0 || v == 3 || v == 5 || v == 6) && pp_epi && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
+    return (v == 0 || v == 3 || v == 5 || v == 6 || v == 12) && pp_epi && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
            (epi != EPI_GELU_BWD || a.ldaux % 8 == 0);
 }
 
@@ -367,11 +396,12 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t s, const Gemm
     b.flags |= ((variant >> 12) & 0xff) << 8;  // bits 12..19 of the knob: column-tile group width GN of gemm_pp (0 = default)
     // default: the persistent ping-pong kernel for the big GEMMs whose epilogue needs no operand load besides bias / u
     if (gemm_uses_pp(epi, a, o.variant)) return launch_gemm_pp(dtype, epi, b, s, o);
-    if (const int S = split_k_slices(epi, a, o); S > 1) {
+    bool deep = false;
+    if (const int S = split_k_slices(epi, a, o, deep); S > 1) {
         GemmArgs q = b;
         q.bias = nullptr; q.out0 = o.scratch; q.ldo0 = a.N; q.ksplit = a.K / S; q.split_stride = (size_t)a.M * a.N;
-        if (dtype == DT_BF16) { if (int rc = launch_cfg<BF16, 64, 64, 2, 2, EPI_STORE_F32, 2>(q, s)) return rc; }
-        else if (dtype == DT_F16) { if (int rc = launch_cfg<F16, 64, 64, 2, 2, EPI_STORE_F32, 2>(q, s)) return rc; }
+        if (dtype == DT_BF16) { if (int rc = deep ? launch_cfg<BF16, 64, 64, 2, 2, EPI_STORE_F32, 2, 128>(q, s) : launch_cfg<BF16, 64, 64, 2, 2, EPI_STORE_F32, 2>(q, s)) return rc; }
+        else if (dtype == DT_F16) { if (int rc = deep ? launch_cfg<F16, 64, 64, 2, 2, EPI_STORE_F32, 2, 128>(q, s) : launch_cfg<F16, 64, 64, 2, 2, EPI_STORE_F32, 2>(q, s)) return rc; }
         else { set_error("gemm: unknown dtype %d", dtype); return MUDPT_ERR_ARG; }
         const unsigned grid = (unsigned)(((size_t)a.M * (a.N / 4) + 255) / 256);
         if (epi == EPI_STORE_F32) hipLaunchKernelGGL((splitk_reduce_kernel<BF16, true>), dim3(grid), dim3(256), 0, s, o.scratch, S, q.split_stride, a.M, a.N, a.bias, a.out0, a.ldo0);
