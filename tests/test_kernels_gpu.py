@@ -134,9 +134,10 @@ def test_gemm_rows_do_not_depend_on_the_kernel_that_ran_them(lib, dtype):
     persistent one: every kernel contracts k in the same order, and (round 4) every T conversion of an epilogue rounds the fp32 VALUE
     (common.h round_to: with -ffp-contract=fast the compiler folded the QuickGELU multiply into the conversion in one kernel and not in the
     other, one ulp apart).  That is what makes a trimmed / bucketed text tower equal the untrimmed one (tests/test_manyclass_gpu.py).
-    The text tower's shapes at 208 class prompts: 5 408 rows (trimmed) against 16 016 (untrimmed)."""
+    The text tower's shapes at 208 class prompts: 5 408 rows (trimmed) against 16 016 (untrimmed); and 450 rows, a grid small enough for the
+    128-deep K-tiles of round 4 (two workgroups per CU: gemm.hip deep_k_tiles)."""
     dt, tt = DT[dtype]
-    M1, M0 = 5408, 16016
+    M2, M1, M0 = 450, 5408, 16016
     g = torch.Generator().manual_seed(11)
     for name, N, K, epi in (("qkv", 1536, 512, 0), ("out", 512, 512, 5), ("fc", 2048, 512, 1), ("proj", 512, 2048, 5), ("dgelu", 2048, 512, 3), ("dfc", 512, 2048, 0)):
         A = torch.randn(M0, K, generator=g).to(tt).cuda()
@@ -144,14 +145,16 @@ def test_gemm_rows_do_not_depend_on_the_kernel_that_ran_them(lib, dtype):
         bias = torch.randn(N, generator=g).cuda()
         auxf = torch.randn(M0, N, generator=g).to(tt).cuda()
         res = {}
-        for M in (M1, M0):
+        for M in (M2, M1, M0):
             out0 = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi == 5 else tt)
             out1 = torch.zeros(M, N, device="cuda", dtype=tt) if epi == 1 else None
             gemm(lib, dt, epi, A[:M], B, bias=bd_or_none(bias, epi), out0=out0, out1=out1, aux=auxf[:M] if epi == 3 else None)
             res[M] = (out0[:M1].clone(), out1[:M1].clone() if out1 is not None else None)
         assert torch.equal(res[M1][0], res[M0][0]), name
+        assert torch.equal(res[M2][0], res[M0][0][:M2]), name
         if epi == 1:
             assert torch.equal(res[M1][1], res[M0][1]), name
+            assert torch.equal(res[M2][1], res[M0][1][:M2]), name
 
 
 def bd_or_none(bias, epi):
