@@ -273,7 +273,8 @@ static int device_cus() {
 // latency chains (wait -> barrier -> fragment reads -> MFMAs per K-tile), and half as many links is what pays: qkv 804 x 2304 x 768 9.8 -> 8.6 us,
 // proj 804 x 768 x 3072 in 3 slices 15.3 -> 13.8; the text tower's 1000 x 512 x 2048 11.2 -> 10.9.  Results are bit-identical to the 64-deep form
 // (same order of the k-steps).  Grids beyond two workgroups per CU lose (fc 804 x 3072 x 768, 624 tiles: 13.7 -> 16.2): they keep 64 (a 64 x 96 x 128
-// tile that would make them fit lost on every shape: fc 13.9 -> 14.3, qkv 8.9 -> 10.0).
+// tile that would make them fit lost on every shape: fc 13.9 -> 14.3, qkv 8.9 -> 10.0; 256-deep tiles at one workgroup per CU: proj 804 x 768 x 3072
+// 16.2 us unsplit against 14.1 for three slices of 128-deep tiles + their sum, the text tower's shapes +-0).
 static inline bool deep_k_tiles(const GemmArgs& a, int slices, int variant) {
     const size_t t64 = (size_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
     return (variant & 0xff) != 12 && a.lo_mode == LO_NONE && (a.K / slices) % 128 == 0 && t64 * slices <= (size_t)2 * device_cus();
