@@ -1466,10 +1466,29 @@ static int vision_backward(mudpt_model* m, int B, float unscale, hipStream_t s) 
     return MUDPT_OK;
 }
 
-// prompt learner backward (fp32, tiny): needs both towers' prompt gradients
-static int prompt_learner_backward(mudpt_model* m, hipStream_t s) {
+// prompt learner backward (fp32, tiny), in two halves: the one that needs only the TEXT tower's prompt gradients is enqueued on the text
+// stream behind that tower's backward, where it overlaps the vision tower's (round 4: 5 of the 15 tiny launches leave the step's serial
+// tail); the other half runs after the join.  Every gradient tensor the halves share is a sum of two terms, one from each: fp32 addition
+// of two terms does not depend on which comes first, so the result is bit-identical to the one-stream order.
+static int prompt_learner_backward_text(mudpt_model* m, hipStream_t s) {
     const mudpt_config& c = m->cfg;
     const int dv = c.v_width, dt = c.t_width, e = c.embed_dim, n = c.n_ctx, D1 = c.depth - 1;
+    float *Pm = m->params, *G = m->grads;
+    if (D1 <= 0) return MUDPT_OK;
+    const int R = D1 * n;
+    // layers >= depth never consume a prompt: rows of d_txt_deep beyond the tower depth stay zero
+    const int used_t = (m->txt.layers - 1 < D1 ? m->txt.layers - 1 : D1) * n;
+    if (used_t < R) HIP_TRY(hipMemsetAsync(m->d_txt_deep + (size_t)used_t * dt, 0, (size_t)(R - used_t) * dt * 4, s));
+    // txt_deep = deep_prompts + visual_ctx_deep_projections(visual_ctx_deep_prompts)   (mudpt.py:175, clip/model.py:539)
+    TRY(launch_add(G + m->off[P_DEEP], m->d_txt_deep, G + m->off[P_DEEP], (size_t)R * dt, s));
+    TRY(launch_sgemm(true, false, e, dv, R, 1.f, m->d_txt_deep, e, Pm + m->off[P_VDEEP], dv, 1.f, G + m->off[P_VW], dv, nullptr, s));
+    TRY(launch_colsum(m->d_txt_deep, R, e, e, G + m->off[P_VB], true, s));
+    TRY(launch_sgemm(false, false, R, dv, e, 1.f, m->d_txt_deep, e, Pm + m->off[P_VW], dv, 1.f, G + m->off[P_VDEEP], dv, nullptr, s));
+    return MUDPT_OK;
+}
+static int prompt_learner_backward_vision(mudpt_model* m, hipStream_t s) {
+    const mudpt_config& c = m->cfg;
+    const int dv = c.v_width, dt = c.t_width, n = c.n_ctx, D1 = c.depth - 1;
     float *Pm = m->params, *G = m->grads;
     // visual_ctx and shared = embed_projection(ctx) both receive d_vprompt0 (clip/model.py:534)
     TRY(launch_add(G + m->off[P_VCTX], m->d_vprompt0, G + m->off[P_VCTX], (size_t)n * dv, s));
@@ -1478,22 +1497,19 @@ static int prompt_learner_backward(mudpt_model* m, hipStream_t s) {
     TRY(launch_sgemm(false, false, n, dt, dv, 1.f, m->d_vprompt0, dv, Pm + m->off[P_EW], dt, 1.f, G + m->off[P_CTX], dt, nullptr, s));
     if (D1 > 0) {
         const int R = D1 * n;
-        // layers >= depth never consume a prompt: rows of d_vis_deep / d_txt_deep beyond the tower depth stay zero
-        const int used_v = (m->vis.layers - 1 < D1 ? m->vis.layers - 1 : D1) * n, used_t = (m->txt.layers - 1 < D1 ? m->txt.layers - 1 : D1) * n;
+        const int used_v = (m->vis.layers - 1 < D1 ? m->vis.layers - 1 : D1) * n;
         if (used_v < R) HIP_TRY(hipMemsetAsync(m->d_vis_deep + (size_t)used_v * dv, 0, (size_t)(R - used_v) * dv * 4, s));
-        if (used_t < R) HIP_TRY(hipMemsetAsync(m->d_txt_deep + (size_t)used_t * dt, 0, (size_t)(R - used_t) * dt * 4, s));
         // vis_deep = deep_projections(deep_prompts) + visual_ctx_deep_prompts   (clip/model.py:537, mudpt.py:127)
         TRY(launch_add(G + m->off[P_VDEEP], m->d_vis_deep, G + m->off[P_VDEEP], (size_t)R * dv, s));
         TRY(launch_sgemm(true, false, dv, dt, R, 1.f, m->d_vis_deep, dv, Pm + m->off[P_DEEP], dt, 1.f, G + m->off[P_DW], dt, nullptr, s));
         TRY(launch_colsum(m->d_vis_deep, R, dv, dv, G + m->off[P_DB], true, s));
         TRY(launch_sgemm(false, false, R, dt, dv, 1.f, m->d_vis_deep, dv, Pm + m->off[P_DW], dt, 1.f, G + m->off[P_DEEP], dt, nullptr, s));
-        // txt_deep = deep_prompts + visual_ctx_deep_projections(visual_ctx_deep_prompts)   (mudpt.py:175, clip/model.py:539)
-        TRY(launch_add(G + m->off[P_DEEP], m->d_txt_deep, G + m->off[P_DEEP], (size_t)R * dt, s));
-        TRY(launch_sgemm(true, false, e, dv, R, 1.f, m->d_txt_deep, e, Pm + m->off[P_VDEEP], dv, 1.f, G + m->off[P_VW], dv, nullptr, s));
-        TRY(launch_colsum(m->d_txt_deep, R, e, e, G + m->off[P_VB], true, s));
-        TRY(launch_sgemm(false, false, R, dv, e, 1.f, m->d_txt_deep, e, Pm + m->off[P_VW], dv, 1.f, G + m->off[P_VDEEP], dv, nullptr, s));
     }
     return MUDPT_OK;
+}
+static int prompt_learner_backward(mudpt_model* m, hipStream_t s) {  // both halves on one stream (the class-parallel phases)
+    TRY(prompt_learner_backward_text(m, s));
+    return prompt_learner_backward_vision(m, s);
 }
 
 extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const int64_t* labels, int32_t B, float grad_scale,
@@ -1511,10 +1527,11 @@ extern "C" int mudpt_forward_backward(mudpt_model* m, const float* images, const
     HIP_TRY(hipEventRecord(m->ev_fork_b, s));
     HIP_TRY(hipStreamWaitEvent(m->s2, m->ev_fork_b, 0));
     TRY(text_backward(m, m->cp_unscale, m->s2));
+    TRY(prompt_learner_backward_text(m, m->s2));
     HIP_TRY(hipEventRecord(m->ev_join_b, m->s2));
     TRY(vision_backward(m, B, m->cp_unscale, s));
     HIP_TRY(hipStreamWaitEvent(s, m->ev_join_b, 0));
-    return prompt_learner_backward(m, s);
+    return prompt_learner_backward_vision(m, s);
 }
 
 // ---- class-parallel phases (SURVEY 8e second axis; the reference runs all C prompts on every replica, trainers/mudpt.py:142-156,230-233) ----

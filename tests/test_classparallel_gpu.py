@@ -19,7 +19,7 @@ import pytest
 import torch
 
 from oracle import mudpt_oracle as O
-from tests.helpers import GoldenCase
+from tests.helpers import FWD_SPLIT_TOL, GoldenCase
 from tests.test_manyclass_gpu import build, check_grads, LOGIT_ATOL, GRAD_RTOL
 
 pytestmark = pytest.mark.gpu
@@ -52,6 +52,16 @@ def test_two_sharded_handles_with_manual_exchange_match_reference_and_unsharded(
     c = GoldenCase("mudpt_vitb16_b4")
     C, B, world = len(c.tokens), len(c.labels), 2
     full = build(c.cfg, c.frozen, c.tokens, c.params, dtype, B)
+    # the unsharded handle on each rank's half batch: the logits the sharded ranks must reproduce BIT FOR BIT (same images per launch, so the
+    # vision tower runs the same kernels; what differs is only who encoded which class) ...
+    logits_h = []
+    for r in range(world):
+        _, lg = full.forward_backward(c.images[r * (B // world):(r + 1) * (B // world)], c.labels[r * (B // world):(r + 1) * (B // world)], return_logits=True)
+        torch.cuda.synchronize()
+        logits_h.append(lg.cpu().clone())
+    logits_h = torch.cat(logits_h)
+    # ... and on the whole batch: loss and gradients of the job.  (Its logits agree with the half-batch ones to rounding only: a TRAINING
+    # forward of a few images splits the contraction of c_proj into a number of slices that depends on the row count)
     loss_f, logits_f = full.forward_backward(c.images, c.labels, return_logits=True)
     torch.cuda.synchronize()
     grads_f = {k: g.detach().cpu().clone() for k, g in full.grads().items()}
@@ -110,8 +120,9 @@ def test_two_sharded_handles_with_manual_exchange_match_reference_and_unsharded(
     # table to ~1e-7, but the T-precision roundings of the 12-block text backward re-randomise under ANY perturbation of their input
     # (each flipped rounding moves every later one), so the text-side gradients agree at the rounding-noise level only -- the level both
     # runs hold against the reference.  The exact statement (same batch, same table: sharded == unsharded to 1e-5) is the next test.
-    assert torch.equal(logits, logits_f), "logits do not depend on which rank encoded a class"
-    assert abs(loss - loss_f.item()) <= 1e-6 * max(1.0, abs(loss))
+    assert torch.equal(logits, logits_h), "logits do not depend on which rank encoded a class"
+    assert (logits - logits_f).abs().max().item() <= FWD_SPLIT_TOL[dtype]
+    assert abs(loss - loss_f.item()) <= (1e-6 if FWD_SPLIT_TOL[dtype] == 0 else FWD_SPLIT_TOL[dtype]) * max(1.0, abs(loss))
     for k, g in grads_f.items():
         rms = g.pow(2).mean().sqrt().item()
         err = (grads[k] - g).abs().max().item()
