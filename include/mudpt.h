@@ -178,7 +178,8 @@ int mudpt_debug_read(mudpt_model* m, const char* name, int32_t batch, float* hos
  * process-global: two models in one process do not interfere.  Defaults are what the product runs; no knob is needed for correct results.
  *
  *   knob               default         meaning
- *   gemm_variant       0               kernel choice of the MFMA GEMMs (gemm.hip launch_epi / gemm_pp.hip; 0 = the default dispatch)
+ *   gemm_variant       0               kernel choice of the MFMA GEMMs (gemm.hip launch_epi / gemm_pp.hip; 0 = the default dispatch; 12 = the default
+ *                                      without the 128-deep K-tiles of the small grids; other values force one tile form: A/B runs)
  *   split_k            1               0 = never split the contraction of the vision tower's small-grid, long-K store GEMMs
  *   fwd_split_k        1               0 = ... of the forward ones (out_proj / c_proj up to 320 tiles of 64 x 64, i.e. <= 8 images of ViT-B): logits
  *                                      of a batch then equal the logits of its chunks bit for bit at EVERY chunk size (default: above that size)
