@@ -366,7 +366,12 @@ static int split_k_slices(int epi, const GemmArgs& a, const GemmOpts& o, bool& d
 bool gemm_uses_pp(int epi, const GemmArgs& a, int variant) {
     const bool pp_epi = epi == EPI_STORE || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32;
     const int v = variant & 0xff;
-    return (v == 0 || v == 3 || v == 5 || v == 6 || v == 12) && pp_epi && (size_t)a.M * a.N >= (size_t)256 * 128 * 512 && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
+    // Size threshold (round 4: half of what it was): from 128 tiles of 256 x 256 on -- half the CUs with a tile each -- the persistent kernel beats the
+    // 128 x 128 / 64 x 64 kernels on the shapes between the small grids and the vision tower's (tools/gemm_bench.py --set mid: the text tower at 1000
+    // classes, 19 000 rows: width 768 proj 97 -> 80, dfc 95 -> 74, dqkv 75 -> 59 us, width 512 dfc 57 -> 49; CoCoOp's vision tower, 12 608 rows: dfc
+    // 81 -> 69; its text tower's N = 2048 shapes 34 -> 26); at 50 tiles (6 336 x 512) it loses (proj 25 -> 34).  Same results bit for bit either way.
+    const size_t tiles = (size_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    return (v == 0 || v == 3 || v == 5 || v == 6 || v == 12) && pp_epi && tiles >= (v == 3 ? 256 : 128) && a.ldo0 % 8 == 0 && (epi != EPI_GELU || a.ldo1 % 8 == 0) &&
            (epi != EPI_GELU_BWD || a.ldaux % 8 == 0);
 }
 

@@ -32,6 +32,12 @@ SMALL_SHAPES = [(f"{nm} M={M}", M, N, K, e) for M, w in ((804, 768), (1000, 512)
                 for nm, N, K, e in (("qkv", 3 * w, w, 0), ("out", w, w, 5), ("fc", 4 * w, w, 1), ("proj", w, 4 * w, 5), ("dgelu", 4 * w, w, 3), ("dfc", w, 4 * w, 0), ("dqkv", w, 3 * w, 0))]
 
 
+# between the small grids and the persistent kernel's territory: the text tower at 1000 classes (19 000 rows; width 512 with ViT-B, 768 with
+# ViT-L/14@336), CoCoOp's 64 x 11 prompts (6 336 rows) and its 64-image vision tower (12 608 rows)
+MID_SHAPES = [(f"{nm} M={M} w={w}", M, N, K, e) for M, w in ((19000, 512), (19000, 768), (6336, 512), (12608, 768))
+              for nm, N, K, e in (("qkv", 3 * w, w, 0), ("out", w, w, 5), ("fc", 4 * w, w, 1), ("proj", w, 4 * w, 5), ("dgelu", 4 * w, w, 3), ("dfc", w, 4 * w, 0), ("dqkv", w, 3 * w, 0))]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
@@ -40,11 +46,11 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--epi", type=int, default=-1, help="only the shapes with this epilogue")
-    ap.add_argument("--set", default="vision", choices=["vision", "text", "small"])
+    ap.add_argument("--set", default="vision", choices=["vision", "text", "small", "mid"])
     ap.add_argument("--library-ref", action="store_true", help="also time torch.nn.functional.linear (rocBLAS / hipBLASLt) on the same operands: a "
                     "known-good reference for what this GPU does on the shape (diagnostic only; the product never calls it)")
     a = ap.parse_args()
-    shapes = {"vision": SHAPES, "text": TEXT_SHAPES, "small": SMALL_SHAPES}[a.set]
+    shapes = {"vision": SHAPES, "text": TEXT_SHAPES, "small": SMALL_SHAPES, "mid": MID_SHAPES}[a.set]
     lib = capi.load()
     dt, tt = (0, torch.bfloat16) if a.dtype == "bf16" else (1, torch.float16)
     variants = [int(v) for v in a.variants.split(",")]
